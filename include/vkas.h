@@ -1,0 +1,206 @@
+/*
+ * vkas.h — C ABI of libvkas.so: the MI355X (gfx950) kernels behind the adaptive-scaling
+ * text-detection forward/backward path.
+ *
+ * The reference (vkit_open_model, pure PyTorch) has no FFI boundary of its own; its boundary for
+ * this path is the nn.Module / loss-callable API.  Each entry point below replaces
+ * the ATen op(s) that a reference call site dispatches to; the file:line given is that call site
+ * (paths relative to /root/reference/vkit_open_model/).  The Python host layer
+ * (vkit_ocr_model_adaptive_scaling_amd/) binds these through ctypes and mirrors the reference's
+ * module API on top.  Nothing here depends on torch: plain pointers, sizes, a HIP stream.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative VKAS_E_* code otherwise (never aborts);
+ *    vkas_last_error() returns a thread-local message for the last failure.
+ *  - `dtype` selects the storage type of activations: VKAS_F32 or VKAS_BF16.  Accumulation is
+ *    always fp32.  Parameters handed over in the reference's layout are always fp32.
+ *  - activations are NHWC: element (b, y, x, c) of a tensor with pixel stride `ld` (elements) lives
+ *    at base[((b*H + y)*W + x)*ld + c].  `ld >= C`, `ld % 8 == 0`, bases 16-byte aligned; a channel
+ *    slice of a wider tensor is expressed by offsetting the base and keeping the wide `ld`
+ *    (this is how torch.cat along C, upernext.py:82,197 / fpn.py:144, disappears).
+ *  - logical channel counts are padded to a multiple of 8 (`Cp`); pad channels hold zeros.
+ *  - all kernels are enqueued on `stream` (a hipStream_t passed as void*); no call synchronises,
+ *    allocates or frees device memory.  Workspaces are caller-provided.
+ */
+#ifndef VKAS_H
+#define VKAS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VKAS_F32 0
+#define VKAS_BF16 1
+
+#define VKAS_OK 0
+#define VKAS_E_ARG (-1)     /* bad shape / alignment / dtype */
+#define VKAS_E_LAUNCH (-2)  /* hipGetLastError() != hipSuccess after a launch */
+
+/* GEMM epilogues (vkas_conv_gemm_fwd) */
+#define VKAS_EPI_NONE 0       /* out = acc + bias */
+#define VKAS_EPI_GELU 1       /* out = acc + bias (pre-activation), out2 = gelu(out)         helper.py:100 */
+#define VKAS_EPI_SCALE_RES 2  /* out2 = acc + bias; out = aux + rowscale[b]*colscale[n]*out2  convnext.py:56-58 */
+#define VKAS_EPI_DGELU 3      /* out = (acc) * gelu'(aux)                                     backward of helper.py:100 */
+#define VKAS_EPI_ADD 4        /* out = acc + bias + aux                                       gradient accumulation */
+#define VKAS_EPI_PATCH 5      /* out scattered to non-overlapping kxk patches: dgrad of helper.py:43-58 */
+
+const char* vkas_last_error(void);
+int vkas_abi_version(void);
+
+/* Geometry of a convolution seen as an implicit GEMM: M = B*Hout*Wout rows, K = KH*KW*Cp columns.
+ * 1x1 / nn.Linear is KH=KW=1, stride 1, pad 0 (helper.py:18-22); 3x3 is pad 1 (helper.py:25-31);
+ * the patchify convs are KH=KW=stride, pad 0 (helper.py:43-58). */
+typedef struct vkas_conv_geom {
+  int B, Hin, Win, Hout, Wout;
+  int Cp;      /* input channels per tap, padded to a multiple of 8 */
+  int ldx;     /* input pixel stride in elements */
+  int KH, KW, stride, pad;
+} vkas_conv_geom;
+
+typedef struct vkas_epilogue {
+  int mode;               /* VKAS_EPI_* */
+  const float* bias;      /* [Np] or NULL */
+  void* out;  long ldo;   /* primary output, row stride (elements) */
+  void* out2; long ldo2;  /* secondary output (GELU, SCALE_RES) or NULL */
+  const void* aux; long ldaux; /* residual / saved pre-activation, same dtype as out */
+  const float* colscale;  /* [Np]   SCALE_RES: block_scale */
+  const float* rowscale;  /* [B] or NULL  SCALE_RES: stochastic-depth keep mask / keep prob */
+  int rows_per_image;     /* Hout*Wout, to index rowscale */
+  int patch;              /* PATCH: patch edge k; rows are the (B,Hs,Ws) grid, columns (ky,kx,c) */
+  int patch_Hs, patch_Ws, patch_Cp;
+} vkas_epilogue;
+
+/* ---- parameter layout conversion (reference layouts -> kernel layouts and back) ------------------ */
+/* w (N,C,KH,KW) fp32 [nn.Conv2d / nn.Linear weight] -> out (Np, KH, KW, Cp) in `dtype`, zero padded.
+ * mode 0: forward operand.  mode 1: dgrad operand of a stride-1 conv: out (Cp_as_rows..) = W flipped and
+ * in/out swapped: out[c][KH-1-ky][KW-1-kx][n] = w[n][c][ky][kx]  (rows = Cp(C), columns (ky,kx,Np)).
+ * mode 2: dgrad operand of a patchify conv: out[(ky,kx,c)][n] = w[n][c][ky][kx] (rows KH*KW*Cp, cols Np). */
+int vkas_pack_conv_weight(const float* w, void* out, int N, int C, int KH, int KW, int Np, int Cp, int mode,
+                          int dtype, void* stream);
+/* gw (Np, KH, KW, Cp) fp32 [wgrad output] -> grad (N,C,KH,KW) fp32, grad += (accumulate != 0) or = */
+int vkas_unpack_conv_wgrad(const float* gw, float* grad, int N, int C, int KH, int KW, int Np, int Cp,
+                           int accumulate, void* stream);
+/* v (n) fp32 -> out (np) fp32 zero padded (bias, LayerNorm affine, block_scale) */
+int vkas_pad_vector(const float* v, float* out, int n, int np, void* stream);
+/* depthwise weight (C,1,7,7) fp32 -> (49, Cp) fp32; flip != 0 rotates the taps by 180 degrees (dgrad operand) */
+int vkas_pack_dw_weight(const float* w, float* out, int C, int Cp, int flip, void* stream);
+/* gw (49, Cp) fp32 -> grad (C,1,7,7) fp32 (+=) */
+int vkas_unpack_dw_wgrad(const float* gw, float* grad, int C, int Cp, int accumulate, void* stream);
+/* image (B,3,H,W) fp32 NCHW [dataset/adaptive_scaling.py:296] -> (B,H,W,8) `dtype`, channels 3..7 zero */
+int vkas_image_nchw_to_nhwc8(const float* img, void* out, int B, int C, int H, int W, int dtype, void* stream);
+/* small head outputs: (B,H,W,ld) `dtype` -> (B,C,H,W) fp32 and the reverse (gradient) direction */
+int vkas_nhwc_to_nchw_f32(const void* x, long ld, float* out, int B, int H, int W, int C, int dtype, void* stream);
+int vkas_nchw_f32_to_nhwc(const float* g, void* out, long ld, int B, int H, int W, int C, int Cp, int dtype, void* stream);
+
+/* ---- implicit-GEMM convolution: helper.py:18-58 (conv1x1 / conv3x3 / pconv2x2 / pconv4x4) -------- */
+/* D[m][n] = epilogue( sum_k A(m,k) * Bw[n][k] ), A gathered from x by `g`; Bw (Np, K) packed `dtype`. */
+int vkas_conv_gemm_fwd(const void* x, const vkas_conv_geom* g, const void* Bw, int Np, const vkas_epilogue* epi,
+                       int dtype, void* stream);
+/* wgrad: gw[n][k] (+)= sum_m dy[m][n] * A(m,k); gw (Np, K) fp32; `ws` >= vkas_conv_gemm_wgrad_ws_bytes().
+ * gw must be zero-filled by the caller (the kernel accumulates split-M partials into it). */
+int vkas_conv_gemm_wgrad(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
+                         int dtype, void* stream);
+/* column sums: out[n] (+)= sum_m y[m][n]   (bias gradients) */
+int vkas_colsum(const void* y, long ld, long M, int Np, float* out, int accumulate, float* ws, size_t ws_bytes,
+                int dtype, void* stream);
+size_t vkas_colsum_ws_bytes(long M, int Np);
+
+/* ---- depthwise 7x7: helper.py:61-73 @ convnext.py:30 ------------------------------------------- */
+/* y = dw7x7(x; w) + bias (+ addend).  w (49, Cp) fp32 (vkas_pack_dw_weight). */
+int vkas_dwconv7x7_fwd(const void* x, long ldx, const float* w, const float* bias, const void* addend, long ldadd,
+                       void* y, long ldy, int B, int H, int W, int Cp, int dtype, void* stream);
+/* gw (49, Cp) and gb (Cp) fp32, overwritten */
+int vkas_dwconv7x7_wgrad(const void* x, long ldx, const void* dy, long lddy, float* gw, float* gb, float* ws,
+                         size_t ws_bytes, int B, int H, int W, int Cp, int dtype, void* stream);
+size_t vkas_dwconv7x7_wgrad_ws_bytes(int B, int H, int W, int Cp);
+
+/* ---- LayerNorm over C (+ optional GELU): helper.py:96-101 --------------------------------------- */
+/* y = act(LN(x) * gamma + beta); stats (M, 2) fp32 = (mean, rstd).  C = logical channels, pad channels -> 0. */
+int vkas_layernorm_fwd(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
+                       float* stats, long M, int C, int Cp, int act_gelu, int dtype, void* stream);
+/* dx from dy; dgamma/dbeta (Cp) fp32 overwritten.  `x` is the forward input, `stats` from forward. */
+int vkas_layernorm_bwd(const void* x, long ldx, const float* gamma, const float* beta, const float* stats,
+                       const void* dy, long lddy, void* dx, long lddx, float* dgamma, float* dbeta, float* ws,
+                       size_t ws_bytes, long M, int C, int Cp, int act_gelu, int dtype, void* stream);
+size_t vkas_layernorm_bwd_ws_bytes(long M, int Cp);
+
+/* ---- block_scale / stochastic depth backward: convnext.py:56-58 ----------------------------------- */
+/* dz = dout * rowscale[b] * colscale[c]; dscale[c] = sum_m dout*rowscale[b]*z; dbias2[c] = sum_m dz */
+int vkas_scale_res_bwd(const void* dout, long lddo, const void* z, long ldz, const float* colscale,
+                       const float* rowscale, int rows_per_image, void* dz, long lddz, float* dscale, float* dbias,
+                       float* ws, size_t ws_bytes, long M, int Cp, int dtype, void* stream);
+size_t vkas_scale_res_bwd_ws_bytes(long M, int Cp);
+
+/* ---- resize: F.interpolate bilinear (upernext.py:79,178-195,237-244), nearest (fpn.py:125-142,197-204) */
+/* mode 0 bilinear (align_corners=False), 1 nearest.  accumulate != 0: y += resize(x) (top-down add). */
+int vkas_resize_fwd(const void* x, long ldx, void* y, long ldy, int B, int Hin, int Win, int Hout, int Wout,
+                    int Cp, int mode, int accumulate, int dtype, void* stream);
+/* dx (+)= resize^T(dy) */
+int vkas_resize_bwd(const void* dy, long lddy, void* dx, long lddx, int B, int Hin, int Win, int Hout, int Wout,
+                    int Cp, int mode, int accumulate, int dtype, void* stream);
+
+/* ---- nn.AdaptiveAvgPool2d(s): upernext.py:62 ------------------------------------------------------ */
+int vkas_adaptive_avgpool_fwd(const void* x, long ldx, void* y, long ldy, int B, int H, int W, int s, int Cp,
+                              int dtype, void* stream);
+int vkas_adaptive_avgpool_bwd(const void* dy, long lddy, void* dx, long lddx, int B, int H, int W, int s, int Cp,
+                              int accumulate, int dtype, void* stream);
+
+/* ---- elementwise ------------------------------------------------------------------------------------ */
+/* y[m][0..Cp) = x[m][0..Cp) (+ y if accumulate): channel-slice copies for concat / its backward */
+int vkas_copy_channels(const void* x, long ldx, void* y, long ldy, long M, int Cp, int accumulate, int dtype,
+                       void* stream);
+/* nn.Softplus() on fp32 maps: adaptive_scaling.py:101,140 */
+int vkas_softplus_fwd(const float* x, float* y, long n, void* stream);
+int vkas_softplus_bwd(const float* x, const float* dy, float* dx, long n, void* stream);
+
+/* ---- dense losses: loss_function/adaptive_scaling.py -------------------------------------------------- */
+typedef struct vkas_rough_loss_cfg {
+  float focal_factor, dice_factor, l1_factor, score_min, height_min; /* :29-35 */
+  float focal_alpha, focal_gamma;                                    /* focal_with_logits.py:21-23 */
+  float out_scale;                                                   /* train.py:413 (1/2), x 1/world */
+} vkas_rough_loss_cfg;
+/* mask_feat/height_feat (B,1,H,W) fp32; gt_mask/gt_score (B,CH,CW) fp32; box = up,left of the crop.
+ * sums: 8 doubles workspace kept for backward; loss: 1 float (already multiplied by out_scale). */
+int vkas_rough_loss_fwd(const float* mask_feat, const float* height_feat, const float* gt_mask,
+                        const float* gt_score, int B, int H, int W, int up, int left, int CH, int CW,
+                        const vkas_rough_loss_cfg* cfg, double* sums, float* loss, void* stream);
+int vkas_rough_loss_bwd(const float* mask_feat, const float* height_feat, const float* gt_mask,
+                        const float* gt_score, int B, int H, int W, int up, int left, int CH, int CW,
+                        const vkas_rough_loss_cfg* cfg, const double* sums, const float* dloss, float* d_mask_feat,
+                        float* d_height_feat, void* stream);
+
+typedef struct vkas_precise_loss_cfg {
+  float pos_l2, neg_l2, offset_l1, reg_l1, angle_ce, dist_l1, loss_factor; /* :136-145 */
+  float smooth_beta;                                                       /* 2.5, :159-165 */
+  float out_scale;
+} vkas_precise_loss_cfg;
+/* prob (B,1,H,W), offset (B,2,H,W), angle (B,4,H,W), dist (B,4,H,W) fp32 NCHW; py/px (B,P) int64;
+ * gt_offsets (B,P,2), gt_angles (B,P,4), gt_dists (B,P,3) fp32. */
+int vkas_precise_loss_fwd(const float* prob, const float* offset, const float* angle, const float* dist,
+                          const float* gt_score, const float* gt_mask, const int64_t* py, const int64_t* px,
+                          const float* gt_offsets, const float* gt_angles, const float* gt_dists, int B, int H,
+                          int W, int up, int left, int CH, int CW, int P, const vkas_precise_loss_cfg* cfg,
+                          double* sums, float* loss, void* stream);
+int vkas_precise_loss_bwd(const float* prob, const float* offset, const float* angle, const float* dist,
+                          const float* gt_score, const float* gt_mask, const int64_t* py, const int64_t* px,
+                          const float* gt_offsets, const float* gt_angles, const float* gt_dists, int B, int H,
+                          int W, int up, int left, int CH, int CW, int P, const vkas_precise_loss_cfg* cfg,
+                          const double* sums, const float* dloss, float* d_prob, float* d_offset, float* d_angle,
+                          float* d_dist, void* stream);
+
+/* ---- optimizer on the flat parameter / gradient buffers: train.py:468-478 ------------------------------ */
+/* sumsq (1 double, zeroed by the call) = sum g^2 */
+int vkas_l2norm_sq(const float* g, long n, double* sumsq, void* stream);
+/* clip coefficient = min(1, max_norm / (sqrt(sumsq) + 1e-6)) [torch clip_grad_norm_]; AdamW (decoupled wd):
+ * p -= lr*wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v/(1-b2^t)) + eps) */
+int vkas_adamw_step(float* p, const float* g, float* m, float* v, long n, const double* sumsq, float max_norm,
+                    float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VKAS_H */

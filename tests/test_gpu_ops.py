@@ -1,0 +1,384 @@
+"""Op-level parity of the HIP kernels (through the C ABI, via the autograd ops) against fp64 CPU math.
+
+Every case runs in fp32 mode (exact-fp32 kernels; tolerance 2e-5 norm-wise, 1e-4 of the peak value
+element-wise) and in bf16 mode (MFMA kernels; inputs and parameters are pre-rounded to bf16 so the only
+differences are output rounding and accumulation order: 4e-3 norm-wise, 2e-2 of the peak element-wise).
+Integer index math (resize / pooling / gather) is exercised at awkward, non-square, non-power-of-two sizes.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+from torch.nn import functional as F
+
+from oracle import torch_oracle as O
+from tests.golden import recipe
+from tests.helpers import golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: (2e-5, 1e-4), torch.bfloat16: (4e-3, 2e-2)}
+
+
+def ops_mod():
+    from vkit_ocr_model_adaptive_scaling_amd import ops
+    return ops
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g, dtype=torch.float64) * scale)
+
+
+def q(t, dtype):
+    """Round to the storage dtype and come back as fp64 (what the kernel will actually see)."""
+    return t.to(dtype).double()
+
+
+def to_act(x_nchw64, dtype, ld_extra=0):
+    """(B,C,H,W) fp64 CPU -> NHWC activation on the GPU, optionally as a channel slice of a wider buffer."""
+    B, C, H, W = x_nchw64.shape
+    Cp = (C + 7) // 8 * 8
+    buf = torch.zeros((B, H, W, Cp + ld_extra), dtype=dtype, device='cuda')
+    buf[..., :C] = x_nchw64.permute(0, 2, 3, 1).to(dtype).cuda()
+    return buf[..., :Cp] if ld_extra else buf
+
+
+def from_act(a, C):
+    return a[..., :C].permute(0, 3, 1, 2).double().cpu()
+
+
+def close(actual, expected, dtype, what=''):
+    rt, mt = TOL[dtype]
+    actual = actual.double().cpu()
+    expected = expected.double().cpu()
+    assert actual.shape == expected.shape, (what, actual.shape, expected.shape)
+    assert torch.isfinite(actual).all(), what
+    r = rel_err(actual, expected)
+    peak = float(expected.abs().max())
+    m = float((actual - expected).abs().max())
+    assert r < rt, f'{what}: norm-wise rel err {r:.3e} >= {rt}'
+    assert m <= mt * max(peak, 1e-30), f'{what}: max abs err {m:.3e} vs peak {peak:.3e}'
+
+
+# ------------------------------------------------------------------------------------------------ conv
+CONV_CASES = [
+    # B, Cin, H, W, N, K, stride, pad
+    (2, 96, 9, 13, 384, 1, 1, 0),
+    (1, 384, 5, 7, 96, 1, 1, 0),
+    (2, 16, 9, 11, 24, 3, 1, 1),
+    (1, 96, 40, 36, 96, 3, 1, 1),
+    (2, 64, 12, 20, 33, 3, 1, 1),
+    (2, 33, 6, 10, 4, 1, 1, 0),
+    (2, 32, 12, 20, 64, 2, 2, 0),
+    (1, 3, 32, 64, 16, 4, 4, 0),
+    (1, 3, 32, 64, 16, 2, 2, 0),
+    (3, 200, 17, 9, 136, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv(case, dtype):
+    ops = ops_mod()
+    B, Cin, H, W, N, K, stride, pad = case
+    x = q(rnd((B, Cin, H, W), 1), dtype)
+    w = q(rnd((N, Cin, K, K), 2, 1.0 / math.sqrt(Cin * K * K)), dtype)
+    b = rnd((N,), 3, 0.1)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br, stride=stride, padding=pad)
+    cot = q(rnd(tuple(ref.shape), 4), dtype)
+    (ref * cot).sum().backward()
+
+    if Cin == 3:
+        xa = ops.ImageToAct.apply(x.float().cuda(), dtype)
+    else:
+        xa = to_act(x, dtype, ld_extra=8).requires_grad_(True)
+    wg = w.float().cuda().requires_grad_(True)
+    bg = b.float().cuda().requires_grad_(True)
+    wparam = wg if K > 1 else wg.view(N, Cin)  # nn.Linear layout for 1x1
+    y = ops.Conv.apply(xa, wparam, bg, stride, pad, Cin != 3)
+    close(from_act(y, N), ref.detach(), dtype, 'conv fwd')
+    if (N + 7) // 8 * 8 != N:
+        assert float(y[..., N:].abs().max()) == 0.0, 'pad channels must stay zero'
+    Np = y.shape[3]
+    cot_a = torch.zeros_like(y)
+    cot_a[..., :N] = cot.permute(0, 2, 3, 1).to(dtype).cuda()
+    y.backward(cot_a)
+    close(wg.grad.view(N, Cin, K, K), wr.grad, dtype, 'conv wgrad')
+    close(bg.grad, br.grad, dtype, 'conv bias grad')
+    if Cin != 3:
+        close(from_act(xa.grad, Cin), xr.grad, dtype, 'conv dgrad')
+
+
+def test_conv_mfma_matches_simple_bitwise_shapes():
+    """bf16: the MFMA kernels and the plain fp32-FMA kernels see identical inputs; results agree to accumulation order."""
+    import os, subprocess, sys
+    # a second process with VKAS_GEMM=simple computes the same case; compare through a file
+    code = r'''
+import torch, sys
+from vkit_ocr_model_adaptive_scaling_amd import ops
+g = torch.Generator().manual_seed(5)
+x = torch.randn((2, 20, 28, 96), generator=g).to(torch.bfloat16).cuda().requires_grad_(True)
+w = (torch.randn((40, 96, 3, 3), generator=g) * 0.03).cuda().requires_grad_(True)
+b = torch.randn((40,), generator=g).cuda().requires_grad_(True)
+y = ops.Conv.apply(x, w, b, 1, 1)
+y.backward(torch.ones_like(y))
+torch.save({'y': y.float().cpu(), 'gx': x.grad.float().cpu(), 'gw': w.grad.cpu()}, sys.argv[1])
+'''
+    import tempfile
+    outs = []
+    for mode in ('mfma', 'simple'):
+        with tempfile.NamedTemporaryFile(suffix='.pt') as f:
+            env = dict(os.environ, VKAS_GEMM=mode)
+            subprocess.run([sys.executable, '-c', code, f.name], check=True, env=env,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            outs.append(torch.load(f.name, weights_only=True))
+    for k in ('y', 'gx', 'gw'):
+        assert rel_err(outs[0][k], outs[1][k]) < 3e-3, k
+
+
+# --------------------------------------------------------------------------------------------- dwconv / layer
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 24, 19, 37), (1, 16, 8, 8), (2, 96, 40, 33), (1, 40, 5, 3)])
+def test_convnext_layer(shape, dtype):
+    """Whole ConvNextBlockLayer (dw7x7, LN, MLP, layer scale, stochastic depth mask, residual) fwd + bwd."""
+    ops = ops_mod()
+    B, C, H, W = shape
+    sd = {
+        'block.0.weight': q(rnd((C, 1, 7, 7), 10, 0.15), torch.float32), 'block.0.bias': rnd((C,), 11, 0.1),
+        'block.2.weight': 1 + rnd((C,), 12, 0.1), 'block.2.bias': rnd((C,), 13, 0.1),
+        'block.3.weight': q(rnd((4 * C, C), 14, 1 / math.sqrt(C)), dtype), 'block.3.bias': rnd((4 * C,), 15, 0.1),
+        'block.5.weight': q(rnd((C, 4 * C), 16, 0.5 / math.sqrt(C)), dtype), 'block.5.bias': rnd((C,), 17, 0.1),
+        'block_scale': (1 + rnd((C, 1, 1), 18, 0.2)),
+    }
+    x = q(rnd(shape, 19), dtype)
+    mask = torch.tensor([1.25, 0.0][:B], dtype=torch.float64) if B > 1 else torch.tensor([1.25], dtype=torch.float64)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    ref = O.convnext_layer(sdr, '', xr, mask.view(-1, 1, 1, 1))
+    cot = q(rnd(shape, 20), dtype)
+    (ref * cot).sum().backward()
+
+    xa = to_act(x, dtype).requires_grad_(True)
+    pg = {k: v.float().cuda().requires_grad_(True) for k, v in sd.items()}
+    y = ops.ConvNextLayer.apply(xa, pg['block.0.weight'], pg['block.0.bias'], pg['block.2.weight'], pg['block.2.bias'],
+                                pg['block.3.weight'], pg['block.3.bias'], pg['block.5.weight'], pg['block.5.bias'],
+                                pg['block_scale'], mask.float().cuda())
+    close(from_act(y, C), ref.detach(), dtype, 'layer fwd')
+    y.backward(to_act(cot, dtype))
+    # bf16: the chain dw -> LN -> GEMM -> GELU -> GEMM re-rounds intermediates; allow 3x the single-op tolerance
+    wide = dtype == torch.bfloat16
+    for k in sd:
+        r = rel_err(pg[k].grad, sdr[k].grad)
+        assert r < (1.5e-2 if wide else 5e-5), (k, r)
+    r = rel_err(from_act(xa.grad, C), xr.grad)
+    assert r < (1.5e-2 if wide else 5e-5), ('dx', r)
+
+
+# ------------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('act', [False, True], ids=['ln', 'ln_gelu'])
+@pytest.mark.parametrize('C', [33, 96, 194, 768, 1536])
+def test_layernorm(C, act, dtype):
+    ops = ops_mod()
+    shape = (2, C, 5, 7)
+    x = q(rnd(shape, 30, 2.0) + 0.5, dtype)
+    g = 1 + rnd((C,), 31, 0.2)
+    b = rnd((C,), 32, 0.2)
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = O.layer_norm_nchw(xr, gr, br)
+    if act:
+        ref = O.gelu(ref)
+    cot = q(rnd(shape, 33), dtype)
+    (ref * cot).sum().backward()
+    xa = to_act(x, dtype, ld_extra=16).requires_grad_(True)
+    gg, bg = g.float().cuda().requires_grad_(True), b.float().cuda().requires_grad_(True)
+    y = ops.LayerNorm.apply(xa, gg, bg, act)
+    close(from_act(y, C), ref.detach(), dtype, 'ln fwd')
+    if y.shape[3] != C:
+        assert float(y[..., C:].abs().max()) == 0.0
+    y.backward(to_act(cot, dtype))
+    close(from_act(xa.grad, C), xr.grad, dtype, 'ln dx')
+    close(gg.grad, gr.grad, dtype, 'ln dgamma')
+    close(bg.grad, br.grad, dtype, 'ln dbeta')
+
+
+# ---------------------------------------------------------------------------------------------- resize / pool
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('mode', [0, 1], ids=['bilinear', 'nearest'])
+@pytest.mark.parametrize('case', recipe.RESIZE_CASES + ((32, 48, 8, 12), (7, 9, 7, 9)))
+def test_resize(case, mode, dtype):
+    ops = ops_mod()
+    hi, wi, ho, wo = case
+    x = q(rnd((2, 16, hi, wi), 40), dtype)
+    xr = x.clone().requires_grad_(True)
+    ref = F.interpolate(xr, size=(ho, wo), mode='bilinear' if mode == 0 else 'nearest')
+    cot = q(rnd(tuple(ref.shape), 41), dtype)
+    (ref * cot).sum().backward()
+    xa = to_act(x, dtype, ld_extra=8).requires_grad_(True)
+    y = ops.Resize.apply(xa, (ho, wo), mode)
+    close(from_act(y, 16), ref.detach(), dtype, 'resize fwd')
+    y.backward(to_act(cot, dtype))
+    close(from_act(xa.grad, 16), xr.grad, dtype, 'resize bwd')
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_resize_matches_reference_goldens(dtype):
+    """F.interpolate outputs stored by the golden generator (same cases the oracle is pinned on)."""
+    ops = ops_mod()
+    g = golden('ops')
+    for (hi, wi, ho, wo) in recipe.RESIZE_CASES:
+        a = torch.from_numpy(recipe.plain_tensor(7, (2, 3, hi, wi)))
+        xa = to_act(a, torch.float32)
+        for mode, name in ((0, 'bilinear'), (1, 'nearest')):
+            y = ops.Resize.apply(xa, (ho, wo), mode)
+            close(from_act(y, 3), torch.from_numpy(g[f'{name}_{hi}x{wi}_{ho}x{wo}']), torch.float32, name)
+    for (hi, wi, s) in recipe.POOL_CASES:
+        a = torch.from_numpy(recipe.plain_tensor(9, (2, 3, hi, wi)))
+        y = ops.AdaptiveAvgPool.apply(to_act(a, torch.float32), s)
+        close(from_act(y, 3), torch.from_numpy(g[f'avgpool_{hi}x{wi}_{s}']), torch.float32, 'avgpool')
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('mode', [0, 1], ids=['bilinear', 'nearest'])
+def test_resize_add_inplace(mode, dtype):
+    ops = ops_mod()
+    dst = q(rnd((2, 8, 12, 20), 42), dtype)
+    src = q(rnd((2, 8, 6, 10), 43), dtype)
+    dr, sr = dst.clone().requires_grad_(True), src.clone().requires_grad_(True)
+    ref = dr + F.interpolate(sr, size=(12, 20), mode='bilinear' if mode == 0 else 'nearest')
+    cot = q(rnd((2, 8, 12, 20), 44), dtype)
+    (ref * cot).sum().backward()
+    da, sa = to_act(dst, dtype).requires_grad_(True), to_act(src, dtype).requires_grad_(True)
+    y = ops.ResizeAdd.apply(da * 1, sa, mode)
+    close(from_act(y, 8), ref.detach(), dtype, 'resize-add fwd')
+    y.backward(to_act(cot, dtype))
+    close(from_act(da.grad, 8), dr.grad, dtype, 'resize-add d dst')
+    close(from_act(sa.grad, 8), sr.grad, dtype, 'resize-add d src')
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', recipe.POOL_CASES)
+def test_adaptive_avgpool(case, dtype):
+    ops = ops_mod()
+    hi, wi, s = case
+    x = q(rnd((2, 24, hi, wi), 45), dtype)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.AdaptiveAvgPool2d(s)(xr)
+    cot = q(rnd(tuple(ref.shape), 46), dtype)
+    (ref * cot).sum().backward()
+    xa = to_act(x, dtype).requires_grad_(True)
+    y = ops.AdaptiveAvgPool.apply(xa, s)
+    close(from_act(y, 24), ref.detach(), dtype, 'avgpool fwd')
+    y.backward(to_act(cot, dtype))
+    close(from_act(xa.grad, 24), xr.grad, dtype, 'avgpool bwd')
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_cat_and_tonchw(dtype):
+    ops = ops_mod()
+    a, b = q(rnd((2, 16, 6, 5), 47), dtype), q(rnd((2, 8, 6, 5), 48), dtype)
+    aa, ba = to_act(a, dtype).requires_grad_(True), to_act(b, dtype, ld_extra=8).requires_grad_(True)
+    cat = ops.Cat.apply(aa, ba)
+    close(from_act(cat, 24), torch.cat([a, b], 1), dtype, 'cat')
+    out = ops.ToNchw.apply(cat, 20)
+    assert out.dtype == torch.float32 and tuple(out.shape) == (2, 20, 6, 5)
+    close(out, torch.cat([a, b], 1)[:, :20], dtype, 'to nchw')
+    cot = rnd((2, 20, 6, 5), 49).float().cuda()
+    out.backward(cot)
+    close(from_act(aa.grad, 16), cot[:, :16].double().cpu().to(dtype).double(), dtype, 'cat grad a')
+    close(from_act(ba.grad, 8)[:, :4], cot[:, 16:20].double().cpu().to(dtype).double(), dtype, 'cat grad b')
+    assert float(from_act(ba.grad, 8)[:, 4:].abs().max()) == 0.0
+
+
+def test_softplus_tails():
+    ops = ops_mod()
+    g = golden('ops')
+    t = torch.from_numpy(recipe.TAIL_POINTS * 6).float().cuda().requires_grad_(True)
+    y = ops.Softplus.apply(t)
+    assert np.allclose(y.detach().cpu().numpy(), g['softplus_tail'], rtol=2e-6, atol=1e-30)
+    y.backward(torch.ones_like(y))
+    tr = torch.from_numpy(recipe.TAIL_POINTS * 6).requires_grad_(True)
+    torch.nn.Softplus()(tr).sum().backward()
+    assert np.allclose(t.grad.cpu().numpy(), tr.grad.numpy(), rtol=2e-6, atol=1e-30)
+
+
+# ---------------------------------------------------------------------------------------------------- losses
+@pytest.mark.parametrize('variant', ['plain', 'edge'])
+def test_losses_vs_reference_goldens(variant):
+    """Fused loss kernels vs the reference's own loss classes (goldens) incl. the masked-out / empty-mask edge cases."""
+    from vkit_ocr_model_adaptive_scaling_amd.loss_function import (
+        Box, AdaptiveScalingRoughLossFunction, AdaptiveScalingRoughLossFunctionConifg,
+        AdaptiveScalingPreciseLossFunction, AdaptiveScalingPreciseLossFunctionConifg)
+    L = recipe.LOSS_TOY
+    g = golden('losses')
+    t = {k: torch.from_numpy(v) for k, v in recipe.loss_inputs(L, variant).items()}
+    c = {k: (v.float().cuda() if v.dtype == torch.float64 else v.cuda()) for k, v in t.items()}
+    box = Box(*L['core_box'])
+    mf, hf = c['mask_feat'].requires_grad_(True), c['height_feat'].requires_grad_(True)
+    rl = AdaptiveScalingRoughLossFunction(AdaptiveScalingRoughLossFunctionConifg())(
+        mf, hf, c['gt_mask'], c['gt_score_rough'], L['shape'], box)
+    rl.backward()
+    assert abs(float(rl) - float(g[f'{variant}/rough_loss'])) < 2e-5 * abs(float(g[f'{variant}/rough_loss']))
+    assert rel_err(mf.grad, g[f'{variant}/g_mask_feat']) < 1e-4
+    assert rel_err(hf.grad, g[f'{variant}/g_height_feat']) < 1e-4
+    p = {k: c[k].requires_grad_(True) for k in ('prob', 'offset', 'angle', 'dist')}
+    pl = AdaptiveScalingPreciseLossFunction(AdaptiveScalingPreciseLossFunctionConifg())(
+        None, p['prob'], p['offset'], p['angle'], p['dist'], c['gt_score_precise'], c['gt_mask'], L['shape'], box,
+        c['py'], c['px'], c['gt_offsets'], c['gt_angles'], c['gt_dists'])
+    pl.backward()
+    assert abs(float(pl) - float(g[f'{variant}/precise_loss'])) < 2e-5 * abs(float(g[f'{variant}/precise_loss']))
+    for k, v in p.items():
+        assert rel_err(v.grad, g[f'{variant}/g_{k}']) < 1e-4, k
+
+
+def test_precise_loss_duplicate_points_accumulate():
+    """Two label points on the same pixel: gradients must add (atomic scatter), as advanced indexing backward does."""
+    from vkit_ocr_model_adaptive_scaling_amd.loss_function import (Box, AdaptiveScalingPreciseLossFunction,
+                                                                   AdaptiveScalingPreciseLossFunctionConifg)
+    B, H, W, P = 1, 16, 16, 4
+    g = torch.Generator().manual_seed(3)
+    mk = lambda *s: torch.randn(*s, generator=g)
+    prob, offset, angle, dist = mk(B, 1, H, W), mk(B, 2, H, W), mk(B, 4, H, W), mk(B, 4, H, W).abs() + 0.1
+    py = torch.tensor([[5, 5, 7, 5]])
+    px = torch.tensor([[6, 6, 2, 6]])
+    gs, gm = torch.rand(B, 12, 12, generator=g), (torch.rand(B, 12, 12, generator=g) > 0.5).float()
+    go, ga, gd = mk(B, P, 2), torch.softmax(mk(B, P, 4), -1), torch.rand(B, P, 3, generator=g)
+    ref_in = [t.double().requires_grad_(True) for t in (prob, offset, angle, dist)]
+    ref = O.precise_loss(*ref_in, gs.double(), gm.double(), (2, 13, 2, 13), py, px, go.double(), ga.double(), gd.double())
+    ref.backward()
+    dev_in = [t.cuda().requires_grad_(True) for t in (prob, offset, angle, dist)]
+    out = AdaptiveScalingPreciseLossFunction(AdaptiveScalingPreciseLossFunctionConifg())(
+        None, *dev_in, gs.cuda(), gm.cuda(), (H, W), Box(2, 13, 2, 13), py.cuda(), px.cuda(), go.cuda(), ga.cuda(), gd.cuda())
+    out.backward()
+    assert abs(float(out) - float(ref)) < 1e-5 * abs(float(ref))
+    for a, b in zip(dev_in, ref_in):
+        assert rel_err(a.grad, b.grad) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------- optimizer
+def test_clip_adamw_matches_torch():
+    import ctypes
+    from vkit_ocr_model_adaptive_scaling_amd.training.optimizer import FlatAdamW
+    torch.manual_seed(0)
+    shapes = [(96, 3, 4, 4), (96,), (384, 96), (1, 1), (33, 7)]
+    ref_params = [torch.nn.Parameter(torch.randn(s, dtype=torch.float64) * 0.1) for s in shapes]
+    opt_ref = torch.optim.AdamW(ref_params, lr=8e-4, betas=(0.9, 0.999), weight_decay=0.01)
+    params = [torch.nn.Parameter(p.detach().float().cuda()) for p in ref_params]
+    opt = FlatAdamW(params, lr=8e-4, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=2.5)
+    for step in range(3):
+        for i, (p, r) in enumerate(zip(params, ref_params)):
+            gr = torch.randn(r.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(100 * step + i)) * (3.0 if step == 1 else 0.01)
+            r.grad = gr.clone()
+            p.grad.copy_(gr.float().cuda())
+        torch.nn.utils.clip_grad_norm_(ref_params, 2.5)
+        opt_ref.step()
+        opt.step(lr=8e-4)
+        opt.zero_grad()
+    for p, r in zip(params, ref_params):
+        assert rel_err(p.detach(), r.detach()) < 2e-6

@@ -1,0 +1,90 @@
+"""World-size-2 gloo run (CPU) of the bucketed gradient reducer with the two-pass step pattern: rough-branch bucket
+reduced after backward #1, backbone buckets only armed for backward #2, result equals the mean of per-rank grads."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+
+class ToyTwoBranch(nn.Module):
+    """Same parameter-sharing pattern as AdaptiveScaling: a shared backbone and two branches used in different passes."""
+
+    def __init__(self):
+        super().__init__()
+        self.backbone = nn.ModuleDict({'stem': nn.Linear(6, 8), 'blocks': nn.ModuleList([nn.Linear(8, 8), nn.Linear(8, 8)])})
+        self.rough_neck = nn.Linear(8, 4)
+        self.rough_char_mask_head = nn.Linear(4, 1)
+        self.precise_neck = nn.Linear(8, 4)
+        self.precise_char_prob_head = nn.Linear(4, 2)
+
+    def features(self, x):
+        x = torch.tanh(self.backbone['stem'](x))
+        for b in self.backbone['blocks']:
+            x = torch.tanh(b(x))
+        return x
+
+    def forward_rough(self, x):
+        return self.rough_char_mask_head(torch.tanh(self.rough_neck(self.features(x))))
+
+    def forward_precise(self, x):
+        return self.precise_char_prob_head(torch.tanh(self.precise_neck(self.features(x))))
+
+
+BUCKETS = [('rough', ('rough_neck.', 'rough_char_mask_head.')), ('precise', ('precise_neck.', 'precise_char_prob_head.')),
+           ('backbone1', ('backbone.blocks.1.',)), ('backbone0', ('backbone.stem.', 'backbone.blocks.0.'))]
+
+
+def _worker(rank, world, port, out):
+    from vkit_ocr_model_adaptive_scaling_amd.training import FlatBuffers, BucketedGradReducer
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        model = ToyTwoBranch()
+        fb = FlatBuffers(model.named_parameters())
+        red = BucketedGradReducer(fb, BUCKETS)
+        g = torch.Generator().manual_seed(100 + rank)
+        xr, xp = torch.randn(5, 6, generator=g), torch.randn(5, 6, generator=g)
+        scale = 0.5 / world
+        red.arm(['rough'])
+        (model.forward_rough(xr).sum() * scale).backward()
+        assert red.launch_log == ['rough'], red.launch_log  # backbone grads are partial: must not be reduced yet
+        red.arm(['precise', 'backbone1', 'backbone0'])
+        (model.forward_precise(xp).pow(2).sum() * scale).backward()
+        assert red.launch_log == ['rough', 'precise', 'backbone1', 'backbone0'], red.launch_log
+        red.flush()
+        # single-process ground truth: mean over ranks of the summed two-pass gradients
+        ref = ToyTwoBranch()
+        ref.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+        for r in range(world):
+            gr = torch.Generator().manual_seed(100 + r)
+            a, b = torch.randn(5, 6, generator=gr), torch.randn(5, 6, generator=gr)
+            (ref.forward_rough(a).sum() * scale).backward()
+            (ref.forward_precise(b).pow(2).sum() * scale).backward()
+        for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7), n
+        # a bucket whose parameters never received a gradient is still reduced by flush()
+        fb.zero_grad()
+        red.launch_log.clear()
+        red.arm(['rough', 'precise'])
+        (model.forward_rough(xr).sum()).backward()
+        red.flush()
+        assert red.launch_log == ['rough', 'precise']
+        if rank == 0:
+            open(out, 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_pass_reducer_world2(tmp_path):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / 'ok')
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    assert open(out).read() == 'ok'

@@ -1,0 +1,278 @@
+// Depthwise 7x7 (pad 3, stride 1) on NHWC activations: helper.py:61-73 used at convnext.py:30.
+//
+// Tiling: one workgroup = 8 x 32 output pixels x one 64-byte channel slice (32 bf16 / 16 fp32 channels).
+// The 14 x 38 input halo tile is staged once in LDS (80-byte pixel pitch: the +16 B pad makes the
+// per-thread 16-byte chunk reads of a 4-pixel strip land on distinct LDS slots), the 49 x slice weights in
+// fp32 next to it.  A thread owns one 16-byte channel chunk and a 1 x 4 strip of outputs: per kernel row it
+// reads 10 input chunks and 7 weight chunks from LDS for 28 * VEC FMAs.  HBM sees each input once per
+// tile plus halo (2.08x from L2), each output once.
+#include "vkas_common.h"
+
+int vkas_colreduce_finalize(const float* partial, long P, int n, int ldp, float* out, int accumulate, hipStream_t st);
+
+namespace {
+
+constexpr int TY = 8, TX = 32, IY = TY + 6, IX = TX + 6;
+constexpr int PIXB = 80;  // bytes per staged pixel: 64 payload + 16 pad
+constexpr int YG = 4;     // y tiles per workgroup in wgrad
+
+template <typename T> struct Vec { static constexpr int N = 16 / sizeof(T); };
+
+template <typename T> __device__ __forceinline__ void load_chunk(const char* p, float* v);
+template <> __device__ __forceinline__ void load_chunk<bf16_t>(const char* p, float* v) {
+  load8(reinterpret_cast<const bf16_t*>(p), v);
+}
+template <> __device__ __forceinline__ void load_chunk<float>(const char* p, float* v) {
+  load4(reinterpret_cast<const float*>(p), v);
+}
+template <typename T> __device__ __forceinline__ void store_chunk(T* p, const float* v);
+template <> __device__ __forceinline__ void store_chunk<bf16_t>(bf16_t* p, const float* v) { store8(p, v); }
+template <> __device__ __forceinline__ void store_chunk<float>(float* p, const float* v) { store4(p, v); }
+
+// stage the (IY x IX) halo tile around output tile origin (y0, x0), channel slice starting at c0
+template <typename T>
+__device__ __forceinline__ void stage_halo(char* tile, const T* __restrict__ x, long ldx, int b, int H, int W, int Cp,
+                                           int y0, int x0, int c0) {
+  constexpr int VEC = Vec<T>::N;
+  for (int i = threadIdx.x; i < IY * IX * 4; i += 256) {
+    const int ch = i & 3;
+    const int p = i >> 2;
+    const int py = p / IX, px = p - py * IX;
+    const int gy = y0 + py - 3, gx = x0 + px - 3;
+    const int c = c0 + ch * VEC;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cp)
+      v = *reinterpret_cast<const uint4*>(x + (((long)b * H + gy) * W + gx) * ldx + c);
+    *reinterpret_cast<uint4*>(tile + p * PIXB + ch * 16) = v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv7x7_fwd_kernel(const T* __restrict__ x, long ldx,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            const T* __restrict__ addend, long ldadd, T* __restrict__ y,
+                                                            long ldy, int H, int W, int Cp, int cslices) {
+  constexpr int VEC = Vec<T>::N;
+  constexpr int CT = 4 * VEC;
+  __shared__ __attribute__((aligned(16))) char tile[IY * IX * PIXB];
+  __shared__ __attribute__((aligned(16))) float wl[49 * CT];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z / cslices;
+  const int c0 = (blockIdx.z - b * cslices) * CT;
+  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+
+  for (int i = tid; i < 49 * CT; i += 256) {
+    const int tap = i / CT, c = i - tap * CT;
+    wl[i] = (c0 + c < Cp) ? w[(long)tap * Cp + c0 + c] : 0.f;
+  }
+  stage_halo<T>(tile, x, ldx, b, H, W, Cp, y0, x0, c0);
+  __syncthreads();
+
+  const int ch = tid & 3, xs = (tid >> 2) & 7, ty = tid >> 5;
+  float acc[4][VEC];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc[j][c] = 0.f;
+
+#pragma unroll 1
+  for (int ky = 0; ky < 7; ++ky) {
+    float in[10][VEC];
+    const char* row = tile + ((ty + ky) * IX + xs * 4) * PIXB + ch * 16;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) load_chunk<T>(row + j * PIXB, in[j]);
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+      float wv[VEC];
+#pragma unroll
+      for (int c = 0; c < VEC; c += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(&wl[(ky * 7 + kx) * CT + ch * VEC + c]);
+        wv[c] = t.x; wv[c + 1] = t.y; wv[c + 2] = t.z; wv[c + 3] = t.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc[j][c] = fmaf(in[j + kx][c], wv[c], acc[j][c]);
+    }
+  }
+
+  const int cb = c0 + ch * VEC;
+  const int oy = y0 + ty;
+  if (cb >= Cp || oy >= H) return;
+  float bv[VEC];
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) bv[c] = bias ? bias[cb + c] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ox = x0 + xs * 4 + j;
+    if (ox >= W) continue;
+    const long pix = ((long)b * H + oy) * W + ox;
+    float o[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) o[c] = acc[j][c] + bv[c];
+    if (addend) {
+      float a[VEC];
+      load_chunk<T>(reinterpret_cast<const char*>(addend + pix * ldadd + cb), a);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) o[c] += a[c];
+    }
+    store_chunk<T>(y + pix * ldy + cb, o);
+  }
+}
+
+// partial[p][tap][c] = sum over the workgroup's pixels of dy[pix][c] * x[pix + tap][c]; row 49 = sum dy
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv7x7_wgrad_kernel(const T* __restrict__ x, long ldx,
+                                                              const T* __restrict__ dy, long lddy,
+                                                              float* __restrict__ partial, int H, int W, int Cp,
+                                                              int cslices) {
+  constexpr int VEC = Vec<T>::N;
+  constexpr int CT = 4 * VEC;
+  __shared__ __attribute__((aligned(16))) char tile[IY * IX * PIXB];
+  __shared__ __attribute__((aligned(16))) char dtile[TY * TX * PIXB];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z / cslices;
+  const int cs = blockIdx.z - b * cslices;
+  const int c0 = cs * CT;
+  const int x0 = blockIdx.x * TX;
+  const int ky = tid >> 5;  // 0..6 taps rows, 7 = bias row
+  const int ch = tid & 3, pl = (tid >> 2) & 7;
+
+  float acc[7][VEC];
+#pragma unroll
+  for (int k = 0; k < 7; ++k)
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc[k][c] = 0.f;
+
+  for (int yt = 0; yt < YG; ++yt) {
+    const int y0 = (blockIdx.y * YG + yt) * TY;
+    if (y0 >= H) break;
+    __syncthreads();
+    stage_halo<T>(tile, x, ldx, b, H, W, Cp, y0, x0, c0);
+    for (int i = tid; i < TY * TX * 4; i += 256) {
+      const int cq = i & 3;
+      const int p = i >> 2;
+      const int py = p / TX, px = p - py * TX;
+      const int gy = y0 + py, gx = x0 + px;
+      const int c = c0 + cq * VEC;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (gy < H && gx < W && c < Cp) v = *reinterpret_cast<const uint4*>(dy + (((long)b * H + gy) * W + gx) * lddy + c);
+      *reinterpret_cast<uint4*>(dtile + p * PIXB + cq * 16) = v;
+    }
+    __syncthreads();
+    for (int p = pl; p < TY * TX; p += 8) {
+      const int py = p / TX, px = p - py * TX;
+      float d[VEC];
+      load_chunk<T>(dtile + p * PIXB + ch * 16, d);
+      if (ky < 7) {
+        const char* row = tile + ((py + ky) * IX + px) * PIXB + ch * 16;
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+          float xin[VEC];
+          load_chunk<T>(row + kx * PIXB, xin);
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) acc[kx][c] = fmaf(d[c], xin[c], acc[kx][c]);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc[0][c] += d[c];
+      }
+    }
+  }
+  // reduce over the 8 pixel lanes (thread bits 2..4)
+#pragma unroll
+  for (int k = 0; k < 7; ++k)
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      float v = acc[k][c];
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      acc[k][c] = v;
+    }
+  const int cb = c0 + ch * VEC;
+  if (pl == 0 && cb < Cp) {
+    const long pidx = ((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    float* dst = partial + pidx * 50 * (long)Cp;
+    if (ky < 7) {
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) dst[(long)(ky * 7 + kx) * Cp + cb + c] = acc[kx][c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) dst[49L * Cp + cb + c] = acc[0][c];
+    }
+  }
+}
+
+}  // namespace
+
+static int dw_check(const char* who, const void* x, long ldx, int B, int H, int W, int Cp) {
+  VKAS_CHECK(x && vkas_aligned16(x), "%s: null/misaligned tensor", who);
+  VKAS_CHECK(B >= 0 && H > 0 && W > 0 && Cp > 0 && Cp % 8 == 0, "%s: bad dims B=%d H=%d W=%d Cp=%d", who, B, H, W, Cp);
+  VKAS_CHECK(ldx >= Cp && ldx % 8 == 0, "%s: bad pixel stride %ld", who, ldx);
+  return VKAS_OK;
+}
+
+extern "C" int vkas_dwconv7x7_fwd(const void* x, long ldx, const float* w, const float* bias, const void* addend,
+                                  long ldadd, void* y, long ldy, int B, int H, int W, int Cp, int dtype,
+                                  void* stream) {
+  int rc = dw_check("vkas_dwconv7x7_fwd", x, ldx, B, H, W, Cp);
+  if (rc) return rc;
+  rc = dw_check("vkas_dwconv7x7_fwd(y)", y, ldy, B, H, W, Cp);
+  if (rc) return rc;
+  VKAS_CHECK(w, "vkas_dwconv7x7_fwd: null weights");
+  if (addend) {
+    rc = dw_check("vkas_dwconv7x7_fwd(addend)", addend, ldadd, B, H, W, Cp);
+    if (rc) return rc;
+  }
+  if (B == 0) return VKAS_OK;
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_dwconv7x7_fwd", {
+    constexpr int CT = 4 * Vec<T>::N;
+    const int cslices = (Cp + CT - 1) / CT;
+    VKAS_CHECK((long)B * cslices <= 65535, "vkas_dwconv7x7_fwd: B*cslices too large");
+    dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, B * cslices);
+    dwconv7x7_fwd_kernel<T><<<grid, 256, 0, vkas_stream(stream)>>>((const T*)x, ldx, w, bias, (const T*)addend, ldadd,
+                                                                   (T*)y, ldy, H, W, Cp, cslices);
+  })
+  VKAS_LAUNCH_CHECK("dwconv7x7_fwd");
+  return VKAS_OK;
+}
+
+static long dw_wgrad_parts(int B, int H, int W) {
+  return (long)B * vkas_cdiv(vkas_cdiv(H, TY), YG) * vkas_cdiv(W, TX);
+}
+
+extern "C" size_t vkas_dwconv7x7_wgrad_ws_bytes(int B, int H, int W, int Cp) {
+  return (size_t)dw_wgrad_parts(B, H, W) * 50 * (size_t)Cp * sizeof(float);
+}
+
+extern "C" int vkas_dwconv7x7_wgrad(const void* x, long ldx, const void* dy, long lddy, float* gw, float* gb,
+                                    float* ws, size_t ws_bytes, int B, int H, int W, int Cp, int dtype,
+                                    void* stream) {
+  int rc = dw_check("vkas_dwconv7x7_wgrad", x, ldx, B, H, W, Cp);
+  if (rc) return rc;
+  rc = dw_check("vkas_dwconv7x7_wgrad(dy)", dy, lddy, B, H, W, Cp);
+  if (rc) return rc;
+  VKAS_CHECK(gw && gb && ws, "vkas_dwconv7x7_wgrad: null output/workspace");
+  VKAS_CHECK(ws_bytes >= vkas_dwconv7x7_wgrad_ws_bytes(B, H, W, Cp), "vkas_dwconv7x7_wgrad: workspace too small");
+  hipStream_t st = vkas_stream(stream);
+  if (B == 0) {
+    (void)hipMemsetAsync(gw, 0, 49L * Cp * sizeof(float), st);
+    (void)hipMemsetAsync(gb, 0, (long)Cp * sizeof(float), st);
+    return VKAS_OK;
+  }
+  const long P = dw_wgrad_parts(B, H, W);
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_dwconv7x7_wgrad", {
+    constexpr int CT = 4 * Vec<T>::N;
+    const int cslices = (Cp + CT - 1) / CT;
+    VKAS_CHECK((long)B * cslices <= 65535, "vkas_dwconv7x7_wgrad: B*cslices too large");
+    dim3 grid((W + TX - 1) / TX, (unsigned)vkas_cdiv(vkas_cdiv(H, TY), YG), B * cslices);
+    dwconv7x7_wgrad_kernel<T><<<grid, 256, 0, st>>>((const T*)x, ldx, (const T*)dy, lddy, ws, H, W, Cp, cslices);
+  })
+  VKAS_LAUNCH_CHECK("dwconv7x7_wgrad");
+  rc = vkas_colreduce_finalize(ws, P, 49 * Cp, 50 * Cp, gw, 0, st);
+  if (rc) return rc;
+  return vkas_colreduce_finalize(ws + 49L * Cp, P, Cp, 50 * Cp, gb, 0, st);
+}

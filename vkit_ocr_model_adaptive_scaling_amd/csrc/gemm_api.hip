@@ -1,0 +1,178 @@
+// C-ABI entry points of the implicit-GEMM family + error plumbing + column sums.
+#include <stdlib.h>
+#include <string.h>
+
+#include "gemm_parts.h"
+
+int vkas_gemm_nt_simple(const void*, const vkas_conv_geom*, const void*, int, const vkas_epilogue*, int, hipStream_t);
+int vkas_gemm_tn_simple(const void*, const vkas_conv_geom*, const void*, long, int, float*, int, hipStream_t);
+int vkas_gemm_nt_mfma_bf16(const void*, const vkas_conv_geom*, const void*, int, const vkas_epilogue*, hipStream_t);
+int vkas_gemm_tn_mfma_bf16(const void*, const vkas_conv_geom*, const void*, long, int, float*, hipStream_t);
+
+static thread_local char g_err[512] = "";
+
+void vkas_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* vkas_last_error(void) { return g_err; }
+extern "C" int vkas_abi_version(void) { return 1; }
+
+static bool force_simple() {
+  static int v = -1;
+  if (v < 0) {
+    const char* s = getenv("VKAS_GEMM");
+    v = (s && strcmp(s, "simple") == 0) ? 1 : 0;
+  }
+  return v == 1;
+}
+
+int vkas_check_geom(const char* who, const void* x, const vkas_conv_geom* g, int Np) {
+  VKAS_CHECK(x && g, "%s: null input", who);
+  VKAS_CHECK(g->B >= 0 && g->Hin > 0 && g->Win > 0 && g->Hout > 0 && g->Wout > 0, "%s: bad spatial dims", who);
+  VKAS_CHECK(g->Cp > 0 && g->Cp % 8 == 0, "%s: Cp=%d must be a positive multiple of 8", who, g->Cp);
+  VKAS_CHECK(g->ldx >= g->Cp && g->ldx % 8 == 0, "%s: ldx=%d must be >= Cp and a multiple of 8", who, g->ldx);
+  VKAS_CHECK(g->KH > 0 && g->KW > 0 && g->stride > 0 && g->pad >= 0, "%s: bad kernel geometry", who);
+  VKAS_CHECK((g->Hin + 2 * g->pad - g->KH) / g->stride + 1 == g->Hout &&
+                 (g->Win + 2 * g->pad - g->KW) / g->stride + 1 == g->Wout,
+             "%s: output size %dx%d inconsistent with input %dx%d k=%dx%d s=%d p=%d", who, g->Hout, g->Wout, g->Hin,
+             g->Win, g->KH, g->KW, g->stride, g->pad);
+  VKAS_CHECK(Np > 0 && Np % 8 == 0, "%s: Np=%d must be a positive multiple of 8", who, Np);
+  VKAS_CHECK(vkas_aligned16(x), "%s: x not 16-byte aligned", who);
+  VKAS_CHECK((long)g->B * g->Hin * g->Win * (long)g->ldx < (1L << 40), "%s: tensor too large", who);
+  return VKAS_OK;
+}
+
+int vkas_check_epilogue(const char* who, const vkas_epilogue* e, int Np) {
+  VKAS_CHECK(e && e->out, "%s: null output", who);
+  VKAS_CHECK(vkas_aligned16(e->out) && e->ldo % 8 == 0, "%s: out misaligned (ldo=%ld)", who, e->ldo);
+  VKAS_CHECK(e->mode >= VKAS_EPI_NONE && e->mode <= VKAS_EPI_PATCH, "%s: bad epilogue mode %d", who, e->mode);
+  if (e->mode != VKAS_EPI_PATCH) VKAS_CHECK(e->ldo >= Np, "%s: ldo=%ld < Np=%d", who, e->ldo, Np);
+  if (e->mode == VKAS_EPI_GELU)
+    VKAS_CHECK(e->out2 && vkas_aligned16(e->out2) && e->ldo2 >= Np && e->ldo2 % 8 == 0, "%s: GELU needs out2", who);
+  if (e->mode == VKAS_EPI_SCALE_RES) {
+    VKAS_CHECK(e->aux && e->colscale && e->rows_per_image > 0, "%s: SCALE_RES needs aux, colscale, rows_per_image", who);
+    VKAS_CHECK(!e->out2 || (vkas_aligned16(e->out2) && e->ldo2 >= Np && e->ldo2 % 8 == 0), "%s: bad out2", who);
+  }
+  if (e->mode == VKAS_EPI_SCALE_RES || e->mode == VKAS_EPI_DGELU || e->mode == VKAS_EPI_ADD)
+    VKAS_CHECK(e->aux && vkas_aligned16(e->aux) && e->ldaux >= Np && e->ldaux % 8 == 0, "%s: bad aux", who);
+  if (e->mode == VKAS_EPI_PATCH)
+    VKAS_CHECK(e->patch > 0 && e->patch_Cp % 8 == 0 && e->patch_Cp > 0 && e->patch * e->patch * e->patch_Cp == Np &&
+                   e->ldo >= e->patch_Cp && e->patch_Hs > 0 && e->patch_Ws > 0,
+               "%s: bad patch scatter geometry", who);
+  return VKAS_OK;
+}
+
+extern "C" int vkas_conv_gemm_fwd(const void* x, const vkas_conv_geom* g, const void* Bw, int Np,
+                                  const vkas_epilogue* epi, int dtype, void* stream) {
+  int rc = vkas_check_geom("vkas_conv_gemm_fwd", x, g, Np);
+  if (rc) return rc;
+  rc = vkas_check_epilogue("vkas_conv_gemm_fwd", epi, Np);
+  if (rc) return rc;
+  VKAS_CHECK(Bw && vkas_aligned16(Bw), "vkas_conv_gemm_fwd: weights null/misaligned");
+  if (epi->mode == VKAS_EPI_PATCH)
+    VKAS_CHECK((long)g->B * g->Hout * g->Wout == (long)g->B * epi->patch_Hs * epi->patch_Ws || g->B == 0,
+               "vkas_conv_gemm_fwd: patch grid does not match the GEMM rows");
+  if (dtype == VKAS_BF16 && !force_simple()) return vkas_gemm_nt_mfma_bf16(x, g, Bw, Np, epi, vkas_stream(stream));
+  return vkas_gemm_nt_simple(x, g, Bw, Np, epi, dtype, vkas_stream(stream));
+}
+
+extern "C" int vkas_conv_gemm_wgrad(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np,
+                                    float* gw, int dtype, void* stream) {
+  int rc = vkas_check_geom("vkas_conv_gemm_wgrad", x, g, Np);
+  if (rc) return rc;
+  VKAS_CHECK(dy && vkas_aligned16(dy) && lddy >= Np && lddy % 8 == 0, "vkas_conv_gemm_wgrad: bad dy (lddy=%ld)", lddy);
+  VKAS_CHECK(gw, "vkas_conv_gemm_wgrad: null gw");
+  if (dtype == VKAS_BF16 && !force_simple()) return vkas_gemm_tn_mfma_bf16(x, g, dy, lddy, Np, gw, vkas_stream(stream));
+  return vkas_gemm_tn_simple(x, g, dy, lddy, Np, gw, dtype, vkas_stream(stream));
+}
+
+// ---- column sums ------------------------------------------------------------------------------------
+namespace {
+static inline long cs_rows_per_block(long M) { long r = vkas_cdiv(M > 0 ? M : 1, 1024); return r < 256 ? 256 : r; }
+
+// partial[blk][c] = sum over this block's rows of y[m][c]; thread = one 8-channel vector, rows strided.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ y, long ld, long M, int Np,
+                                                             long rows_per_block, float* __restrict__ partial) {
+  const int nvec = Np >> 3;
+  const int lanes_r = 256 / nvec > 0 ? 256 / nvec : 1;  // row lanes per block (nvec <= 256 checked by host)
+  const int v = threadIdx.x % nvec;
+  const int rl = threadIdx.x / nvec;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long mbeg = (long)blockIdx.x * rows_per_block;
+  const long mend = mbeg + rows_per_block < M ? mbeg + rows_per_block : M;
+  if (rl < lanes_r) {
+    for (long m = mbeg + rl; m < mend; m += lanes_r) {
+      float t[8];
+      load8(y + m * ld + v * 8, t);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += t[i];
+    }
+  }
+  __shared__ float red[256 * 8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = acc[i];
+  __syncthreads();
+  if (rl == 0) {
+    for (int r = 1; r < lanes_r; ++r)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += red[(r * nvec + v) * 8 + i];
+    float* dst = partial + (long)blockIdx.x * Np + v * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = acc[i];
+  }
+}
+}  // namespace
+
+// out[c] (+)= sum_p partial[p][c]; 32 columns x 8 row lanes per block, fixed summation order => deterministic.
+__global__ __launch_bounds__(256) void vkas_colreduce_finalize_kernel(const float* __restrict__ partial, long P, int n,
+                                                                      int ldp, float* __restrict__ out,
+                                                                      int accumulate) {
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float s = 0.f;
+  if (c < n)
+    for (long p = rl; p < P; p += 8) s += partial[p * ldp + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < n) {
+#pragma unroll
+    for (int r = 1; r < 8; ++r) s += red[r][cl];
+    out[c] = accumulate ? out[c] + s : s;
+  }
+}
+
+int vkas_colreduce_finalize(const float* partial, long P, int n, int ldp, float* out, int accumulate,
+                            hipStream_t st) {
+  vkas_colreduce_finalize_kernel<<<(unsigned)vkas_cdiv(n, 32), 256, 0, st>>>(partial, P, n, ldp, out, accumulate);
+  VKAS_LAUNCH_CHECK("colreduce_finalize");
+  return VKAS_OK;
+}
+
+extern "C" size_t vkas_colsum_ws_bytes(long M, int Np) {
+  return (size_t)vkas_cdiv(M > 0 ? M : 1, cs_rows_per_block(M)) * (size_t)Np * sizeof(float);
+}
+
+extern "C" int vkas_colsum(const void* y, long ld, long M, int Np, float* out, int accumulate, float* ws,
+                           size_t ws_bytes, int dtype, void* stream) {
+  VKAS_CHECK(y && out && ws, "vkas_colsum: null pointer");
+  VKAS_CHECK(Np > 0 && Np % 8 == 0 && Np <= 2048, "vkas_colsum: Np=%d must be a multiple of 8, <= 2048", Np);
+  VKAS_CHECK(ld >= Np && ld % 8 == 0 && vkas_aligned16(y), "vkas_colsum: bad ld/alignment");
+  VKAS_CHECK(ws_bytes >= vkas_colsum_ws_bytes(M, Np), "vkas_colsum: workspace too small");
+  if (M <= 0) {
+    if (!accumulate) (void)hipMemsetAsync(out, 0, Np * sizeof(float), vkas_stream(stream));
+    return VKAS_OK;
+  }
+  const long rpb = cs_rows_per_block(M);
+  const long P = vkas_cdiv(M, rpb);
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_colsum", {
+    colsum_partial_kernel<T><<<(unsigned)P, 256, 0, vkas_stream(stream)>>>((const T*)y, ld, M, Np, rpb, ws);
+  })
+  VKAS_LAUNCH_CHECK("colsum_partial");
+  return vkas_colreduce_finalize(ws, P, Np, Np, out, accumulate, vkas_stream(stream));
+}

@@ -1,0 +1,331 @@
+// LayerNorm over the channel axis of NHWC activations (+ optional exact GELU), forward and backward:
+// helper.py:96-101 as used in convnext.py:32,85,121, upernext.py:28,42, fpn.py:25,35,45.
+// Also the backward of the layer-scale / stochastic-depth / residual epilogue (convnext.py:56-58).
+//
+// One pixel row is handled by a group of G lanes (G = smallest power of two >= Cp/8, max 64), each lane
+// holding 8-channel vectors in registers, so a row is read exactly once; statistics are two-pass in
+// registers (mean, then centred variance).  Backward keeps per-thread dgamma/dbeta partial sums over the
+// rows a workgroup walks, reduces them through LDS and writes one partial row per workgroup; a fixed-order
+// finalize kernel adds the partials (deterministic, no float atomics).
+#include "vkas_common.h"
+
+int vkas_colreduce_finalize(const float* partial, long P, int n, int ldp, float* out, int accumulate, hipStream_t st);
+
+namespace {
+
+constexpr int MAXV = 4;  // vectors per lane: Cp <= 8 * 64 * 4 = 2048
+
+__device__ __forceinline__ float group_sum(float v, int G) {
+  for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int pick_group(int nvec) {
+  int g = 1;
+  while (g < nvec && g < 64) g <<= 1;
+  return g;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, long ldx,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y, long ldy,
+                                                            float* __restrict__ stats, long M, int C, int Cp, int G,
+                                                            int act_gelu) {
+  const int nvec = Cp >> 3;
+  const int gl = threadIdx.x & (G - 1);
+  const long m = (long)blockIdx.x * (256 / G) + threadIdx.x / G;
+  const bool row_ok = m < M;
+  float v[MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vi = gl + i * G;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[i][c] = 0.f;
+    if (row_ok && vi < nvec) load8(x + m * ldx + vi * 8, v[i]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s += (vi * 8 + c < C) ? v[i][c] : 0.f;
+  }
+  s = group_sum(s, G);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vi = gl + i * G;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float d = v[i][c] - mean;
+      q += (vi < nvec && vi * 8 + c < C) ? d * d : 0.f;
+    }
+  }
+  q = group_sum(q, G);
+  const float rstd = rsqrtf(q / (float)C + 1e-6f);
+  if (!row_ok) return;
+  if (gl == 0 && stats) {
+    stats[2 * m] = mean;
+    stats[2 * m + 1] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vi = gl + i * G;
+    if (vi >= nvec) continue;
+    float o[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int cc = vi * 8 + c;
+      float u = 0.f;
+      if (cc < C) {
+        u = (v[i][c] - mean) * rstd * gamma[cc] + beta[cc];
+        if (act_gelu) u = gelu_f(u);
+      }
+      o[c] = u;
+    }
+    store8(y + m * ldy + vi * 8, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, long ldx,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ stats, const T* __restrict__ dy,
+                                                            long lddy, T* __restrict__ dx, long lddx,
+                                                            float* __restrict__ partial, long M, int C, int Cp, int G,
+                                                            int act_gelu, long rows_per_block) {
+  const int nvec = Cp >> 3;
+  const int gl = threadIdx.x & (G - 1);
+  const int rl = threadIdx.x / G;
+  const int rpi = 256 / G;  // rows per iteration
+  const long mbeg = (long)blockIdx.x * rows_per_block;
+  const long mend = mbeg + rows_per_block < M ? mbeg + rows_per_block : M;
+  float dg[MAXV][8], db[MAXV][8], gm[MAXV][8], bt[MAXV][8];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vi = gl + i * G;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      dg[i][c] = 0.f;
+      db[i][c] = 0.f;
+      const int cc = vi * 8 + c;
+      gm[i][c] = (vi < nvec && cc < C) ? gamma[cc] : 0.f;
+      bt[i][c] = (vi < nvec && cc < C) ? beta[cc] : 0.f;
+    }
+  }
+  for (long m0 = mbeg; m0 < mend; m0 += rpi) {
+    const long m = m0 + rl;
+    const bool ok = m < mend;
+    const float mean = ok ? stats[2 * m] : 0.f;
+    const float rstd = ok ? stats[2 * m + 1] : 0.f;
+    float xh[MAXV][8], g[MAXV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int vi = gl + i * G;
+      float xv[8], dv[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { xv[c] = 0.f; dv[c] = 0.f; }
+      if (ok && vi < nvec) {
+        load8(x + m * ldx + vi * 8, xv);
+        load8(dy + m * lddy + vi * 8, dv);
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const bool cok = ok && vi < nvec && (vi * 8 + c < C);
+        const float h = cok ? (xv[c] - mean) * rstd : 0.f;
+        float gg = cok ? dv[c] : 0.f;
+        if (act_gelu) gg *= dgelu_f(h * gm[i][c] + bt[i][c]);
+        xh[i][c] = h;
+        g[i][c] = gg;
+        dg[i][c] += gg * h;
+        db[i][c] += gg;
+        const float dxh = gg * gm[i][c];
+        s1 += dxh;
+        s2 += dxh * h;
+      }
+    }
+    s1 = group_sum(s1, G) / (float)C;
+    s2 = group_sum(s2, G) / (float)C;
+    if (ok) {
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int vi = gl + i * G;
+        if (vi >= nvec) continue;
+        float o[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const bool cok = vi * 8 + c < C;
+          o[c] = cok ? rstd * (g[i][c] * gm[i][c] - s1 - xh[i][c] * s2) : 0.f;
+        }
+        store8(dx + m * lddx + vi * 8, o);
+      }
+    }
+  }
+  // reduce the per-thread column sums over the row lanes of the workgroup
+  __shared__ float red[256 * 8];
+  float* prow = partial + (long)blockIdx.x * 2 * Cp;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    if (i * G < nvec) {  // uniform over the workgroup
+      const int vi = gl + i * G;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 8; ++c) red[threadIdx.x * 8 + c] = pass ? db[i][c] : dg[i][c];
+        __syncthreads();
+        if (rl == 0 && vi < nvec) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            float s = 0.f;
+            for (int r = 0; r < rpi; ++r) s += red[(r * G + gl) * 8 + c];
+            prow[(pass ? Cp : 0) + vi * 8 + c] = s;
+          }
+        }
+      }
+    }
+  }
+}
+
+// dz = dout*rs[b]*cs[c]; partial sums of dout*rs*z (-> dscale) and dz (-> dbias)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_res_bwd_kernel(const T* __restrict__ dout, long lddo,
+                                                            const T* __restrict__ z, long ldz,
+                                                            const float* __restrict__ colscale,
+                                                            const float* __restrict__ rowscale, int rows_per_image,
+                                                            T* __restrict__ dz, long lddz, float* __restrict__ partial,
+                                                            long M, int Cp, long rows_per_block) {
+  const int nvec = Cp >> 3;
+  const int lanes_r = 256 / nvec;
+  const int v = threadIdx.x % nvec;
+  const int rl = threadIdx.x / nvec;
+  float a1[8], a2[8], cs[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { a1[c] = 0.f; a2[c] = 0.f; cs[c] = colscale[v * 8 + c]; }
+  const long mbeg = (long)blockIdx.x * rows_per_block;
+  const long mend = mbeg + rows_per_block < M ? mbeg + rows_per_block : M;
+  if (rl < lanes_r) {
+    for (long m = mbeg + rl; m < mend; m += lanes_r) {
+      float d[8], zz[8], o[8];
+      load8(dout + m * lddo + v * 8, d);
+      load8(z + m * ldz + v * 8, zz);
+      const float rs = rowscale ? rowscale[m / rows_per_image] : 1.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float t = d[c] * rs;
+        a1[c] += t * zz[c];
+        o[c] = t * cs[c];
+        a2[c] += o[c];
+      }
+      store8(dz + m * lddz + v * 8, o);
+    }
+  }
+  __shared__ float red[256 * 8];
+  float* prow = partial + (long)blockIdx.x * 2 * Cp;
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) red[threadIdx.x * 8 + c] = pass ? a2[c] : a1[c];
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float s = 0.f;
+        for (int r = 0; r < lanes_r; ++r) s += red[(r * nvec + v) * 8 + c];
+        prow[(pass ? Cp : 0) + v * 8 + c] = s;
+      }
+    }
+  }
+}
+
+static inline long rows_per_block_for(long M, long quantum) {
+  long r = vkas_cdiv(M > 0 ? M : 1, 1024);
+  if (r < 256) r = 256;
+  return vkas_cdiv(r, quantum) * quantum;
+}
+
+}  // namespace
+
+extern "C" int vkas_layernorm_fwd(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
+                                  float* stats, long M, int C, int Cp, int act_gelu, int dtype, void* stream) {
+  VKAS_CHECK(x && y && gamma && beta, "vkas_layernorm_fwd: null pointer");
+  VKAS_CHECK(Cp > 0 && Cp % 8 == 0 && Cp <= 2048 && C > 0 && C <= Cp, "vkas_layernorm_fwd: bad C=%d Cp=%d", C, Cp);
+  VKAS_CHECK(ldx >= Cp && ldy >= Cp && ldx % 8 == 0 && ldy % 8 == 0 && vkas_aligned16(x) && vkas_aligned16(y),
+             "vkas_layernorm_fwd: bad strides/alignment");
+  if (M <= 0) return VKAS_OK;
+  const int G = pick_group(Cp >> 3);
+  const long rows = 256 / G;
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_layernorm_fwd", {
+    layernorm_fwd_kernel<T><<<(unsigned)vkas_cdiv(M, rows), 256, 0, vkas_stream(stream)>>>(
+        (const T*)x, ldx, gamma, beta, (T*)y, ldy, stats, M, C, Cp, G, act_gelu);
+  })
+  VKAS_LAUNCH_CHECK("layernorm_fwd");
+  return VKAS_OK;
+}
+
+extern "C" size_t vkas_layernorm_bwd_ws_bytes(long M, int Cp) {
+  const int G = pick_group(Cp >> 3);
+  const long rpb = rows_per_block_for(M, 256 / G);
+  return (size_t)vkas_cdiv(M > 0 ? M : 1, rpb) * 2 * (size_t)Cp * sizeof(float);
+}
+
+extern "C" int vkas_layernorm_bwd(const void* x, long ldx, const float* gamma, const float* beta, const float* stats,
+                                  const void* dy, long lddy, void* dx, long lddx, float* dgamma, float* dbeta,
+                                  float* ws, size_t ws_bytes, long M, int C, int Cp, int act_gelu, int dtype,
+                                  void* stream) {
+  VKAS_CHECK(x && dy && dx && gamma && beta && stats && dgamma && dbeta && ws, "vkas_layernorm_bwd: null pointer");
+  VKAS_CHECK(Cp > 0 && Cp % 8 == 0 && Cp <= 2048 && C > 0 && C <= Cp, "vkas_layernorm_bwd: bad C=%d Cp=%d", C, Cp);
+  VKAS_CHECK(ldx >= Cp && lddy >= Cp && lddx >= Cp && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 &&
+                 vkas_aligned16(x) && vkas_aligned16(dy) && vkas_aligned16(dx),
+             "vkas_layernorm_bwd: bad strides/alignment");
+  VKAS_CHECK(ws_bytes >= vkas_layernorm_bwd_ws_bytes(M, Cp), "vkas_layernorm_bwd: workspace too small");
+  hipStream_t st = vkas_stream(stream);
+  if (M <= 0) {
+    (void)hipMemsetAsync(dgamma, 0, Cp * sizeof(float), st);
+    (void)hipMemsetAsync(dbeta, 0, Cp * sizeof(float), st);
+    return VKAS_OK;
+  }
+  const int G = pick_group(Cp >> 3);
+  const long rpb = rows_per_block_for(M, 256 / G);
+  const long P = vkas_cdiv(M, rpb);
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_layernorm_bwd", {
+    layernorm_bwd_kernel<T><<<(unsigned)P, 256, 0, st>>>((const T*)x, ldx, gamma, beta, stats, (const T*)dy, lddy,
+                                                         (T*)dx, lddx, ws, M, C, Cp, G, act_gelu, rpb);
+  })
+  VKAS_LAUNCH_CHECK("layernorm_bwd");
+  int rc = vkas_colreduce_finalize(ws, P, Cp, 2 * Cp, dgamma, 0, st);
+  if (rc) return rc;
+  return vkas_colreduce_finalize(ws + Cp, P, Cp, 2 * Cp, dbeta, 0, st);
+}
+
+extern "C" size_t vkas_scale_res_bwd_ws_bytes(long M, int Cp) {
+  const long rpb = rows_per_block_for(M, 1);
+  return (size_t)vkas_cdiv(M > 0 ? M : 1, rpb) * 2 * (size_t)Cp * sizeof(float);
+}
+
+extern "C" int vkas_scale_res_bwd(const void* dout, long lddo, const void* z, long ldz, const float* colscale,
+                                  const float* rowscale, int rows_per_image, void* dz, long lddz, float* dscale,
+                                  float* dbias, float* ws, size_t ws_bytes, long M, int Cp, int dtype, void* stream) {
+  VKAS_CHECK(dout && z && colscale && dz && dscale && dbias && ws, "vkas_scale_res_bwd: null pointer");
+  VKAS_CHECK(Cp > 0 && Cp % 8 == 0 && Cp <= 2048 && rows_per_image > 0, "vkas_scale_res_bwd: bad Cp=%d", Cp);
+  VKAS_CHECK(lddo >= Cp && ldz >= Cp && lddz >= Cp && lddo % 8 == 0 && ldz % 8 == 0 && lddz % 8 == 0 &&
+                 vkas_aligned16(dout) && vkas_aligned16(z) && vkas_aligned16(dz),
+             "vkas_scale_res_bwd: bad strides/alignment");
+  const long rpb = rows_per_block_for(M, 1);
+  const long P = vkas_cdiv(M > 0 ? M : 1, rpb);
+  VKAS_CHECK(ws_bytes >= (size_t)P * 2 * Cp * sizeof(float), "vkas_scale_res_bwd: workspace too small");
+  hipStream_t st = vkas_stream(stream);
+  if (M <= 0) {
+    (void)hipMemsetAsync(dscale, 0, Cp * sizeof(float), st);
+    (void)hipMemsetAsync(dbias, 0, Cp * sizeof(float), st);
+    return VKAS_OK;
+  }
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_scale_res_bwd", {
+    scale_res_bwd_kernel<T><<<(unsigned)P, 256, 0, st>>>((const T*)dout, lddo, (const T*)z, ldz, colscale, rowscale,
+                                                         rows_per_image, (T*)dz, lddz, ws, M, Cp, rpb);
+  })
+  VKAS_LAUNCH_CHECK("scale_res_bwd");
+  int rc = vkas_colreduce_finalize(ws, P, Cp, 2 * Cp, dscale, 0, st);
+  if (rc) return rc;
+  return vkas_colreduce_finalize(ws + Cp, P, Cp, 2 * Cp, dbias, 0, st);
+}

@@ -1,0 +1,262 @@
+// Layout conversions between the reference's parameter / tensor layouts (fp32, (N,C,KH,KW), NCHW) and the
+// kernels' layouts (packed K-major weights, NHWC activations), plus small elementwise kernels.
+#include "vkas_common.h"
+
+namespace {
+
+template <typename T>
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int N, int C, int KH, int KW,
+                                        int Np, int Cp, int mode, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int n, c, ky, kx;
+    long r = i;
+    if (mode == 0) {  // [n][ky][kx][c]
+      c = (int)(r % Cp); r /= Cp;
+      kx = (int)(r % KW); r /= KW;
+      ky = (int)(r % KH); r /= KH;
+      n = (int)r;
+    } else if (mode == 1) {  // [c][ky'][kx'][n], taps rotated by 180 degrees
+      n = (int)(r % Np); r /= Np;
+      kx = KW - 1 - (int)(r % KW); r /= KW;
+      ky = KH - 1 - (int)(r % KH); r /= KH;
+      c = (int)r;
+    } else {  // [(ky,kx,c)][n]
+      n = (int)(r % Np); r /= Np;
+      c = (int)(r % Cp); r /= Cp;
+      kx = (int)(r % KW); r /= KW;
+      ky = (int)r;
+    }
+    float v = 0.f;
+    if (n < N && c < C) v = w[(((long)n * C + c) * KH + ky) * KW + kx];
+    out[i] = from_f32<T>(v);
+  }
+}
+
+__global__ void unpack_conv_wgrad_kernel(const float* __restrict__ gw, float* __restrict__ grad, int N, int C, int KH,
+                                         int KW, int Np, int Cp, int accumulate, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i;  // index into grad (N,C,KH,KW)
+    const int kx = (int)(r % KW); r /= KW;
+    const int ky = (int)(r % KH); r /= KH;
+    const int c = (int)(r % C); r /= C;
+    const int n = (int)r;
+    const float v = gw[(((long)n * KH + ky) * KW + kx) * Cp + c];
+    grad[i] = accumulate ? grad[i] + v : v;
+  }
+}
+
+__global__ void pad_vector_kernel(const float* __restrict__ v, float* __restrict__ out, int n, int np) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < np) out[i] = i < n ? v[i] : 0.f;
+}
+
+__global__ void pack_dw_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int C, int Cp, int flip) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 49*Cp
+  if (i >= 49 * Cp) return;
+  const int tap = i / Cp, c = i - tap * Cp;
+  const int src_tap = flip ? 48 - tap : tap;
+  out[i] = c < C ? w[(long)c * 49 + src_tap] : 0.f;
+}
+
+__global__ void unpack_dw_wgrad_kernel(const float* __restrict__ gw, float* __restrict__ grad, int C, int Cp,
+                                       int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over C*49
+  if (i >= C * 49) return;
+  const int c = i / 49, tap = i - c * 49;
+  const float v = gw[(long)tap * Cp + c];
+  grad[i] = accumulate ? grad[i] + v : v;
+}
+
+template <typename T>
+__global__ void image_to_nhwc8_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int C, int H, int W) {
+  const long total = (long)B * H * W;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+    const long hw = (long)H * W;
+    const int b = (int)(p / hw);
+    const long r = p - (long)b * hw;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < C; ++c) v[c] = img[((long)b * C + c) * hw + r];
+    store8(out + p * 8, v);
+  }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, long ld, float* __restrict__ out, int B, long HW, int C) {
+  const long total = (long)B * C * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i % HW;
+    const long bc = i / HW;
+    const int c = (int)(bc % C);
+    const long b = bc / C;
+    out[i] = to_f32(x[(b * HW + r) * ld + c]);
+  }
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ g, T* __restrict__ out, long ld, int B, long HW, int C,
+                                    int Cp) {
+  const long total = (long)B * HW * Cp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cp);
+    const long p = i / Cp;
+    const long b = p / HW;
+    const long r = p - b * HW;
+    const float v = c < C ? g[(b * C + c) * HW + r] : 0.f;
+    out[p * ld + c] = from_f32<T>(v);
+  }
+}
+
+template <typename T>
+__global__ void copy_channels_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, long M, int nvec,
+                                     int accumulate) {
+  const long total = M * nvec;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % nvec);
+    const long m = i / nvec;
+    float t[8];
+    load8(x + m * ldx + v * 8, t);
+    if (accumulate) {
+      float u[8];
+      load8(y + m * ldy + v * 8, u);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] += u[k];
+    }
+    store8(y + m * ldy + v * 8, t);
+  }
+}
+
+// nn.Softplus(beta=1, threshold=20): adaptive_scaling.py:101,140
+__global__ void softplus_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    y[i] = v > 20.f ? v : log1pf(expf(v));
+  }
+}
+__global__ void softplus_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                    long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    dx[i] = v > 20.f ? dy[i] : dy[i] / (1.f + expf(-v));
+  }
+}
+
+static inline unsigned grid1d(long total, int bs = 256) {
+  long g = vkas_cdiv(total, bs);
+  if (g > 16384) g = 16384;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int vkas_pack_conv_weight(const float* w, void* out, int N, int C, int KH, int KW, int Np, int Cp, int mode,
+                                     int dtype, void* stream) {
+  VKAS_CHECK(w && out, "vkas_pack_conv_weight: null pointer");
+  VKAS_CHECK(N > 0 && C > 0 && KH > 0 && KW > 0 && Np >= N && Cp >= C && Np % 8 == 0 && Cp % 8 == 0,
+             "vkas_pack_conv_weight: bad dims N=%d C=%d Np=%d Cp=%d", N, C, Np, Cp);
+  VKAS_CHECK(mode >= 0 && mode <= 2, "vkas_pack_conv_weight: bad mode %d", mode);
+  const long total = (long)Np * KH * KW * Cp;
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_pack_conv_weight", {
+    pack_conv_weight_kernel<T><<<grid1d(total), 256, 0, vkas_stream(stream)>>>(w, (T*)out, N, C, KH, KW, Np, Cp, mode,
+                                                                              total);
+  })
+  VKAS_LAUNCH_CHECK("pack_conv_weight");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_unpack_conv_wgrad(const float* gw, float* grad, int N, int C, int KH, int KW, int Np, int Cp,
+                                      int accumulate, void* stream) {
+  VKAS_CHECK(gw && grad, "vkas_unpack_conv_wgrad: null pointer");
+  VKAS_CHECK(N > 0 && C > 0 && Np >= N && Cp >= C, "vkas_unpack_conv_wgrad: bad dims");
+  const long total = (long)N * C * KH * KW;
+  unpack_conv_wgrad_kernel<<<grid1d(total), 256, 0, vkas_stream(stream)>>>(gw, grad, N, C, KH, KW, Np, Cp, accumulate,
+                                                                          total);
+  VKAS_LAUNCH_CHECK("unpack_conv_wgrad");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_pad_vector(const float* v, float* out, int n, int np, void* stream) {
+  VKAS_CHECK(v && out && n > 0 && np >= n, "vkas_pad_vector: bad arguments");
+  pad_vector_kernel<<<(unsigned)vkas_cdiv(np, 256), 256, 0, vkas_stream(stream)>>>(v, out, n, np);
+  VKAS_LAUNCH_CHECK("pad_vector");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_pack_dw_weight(const float* w, float* out, int C, int Cp, int flip, void* stream) {
+  VKAS_CHECK(w && out && C > 0 && Cp >= C && Cp % 8 == 0, "vkas_pack_dw_weight: bad arguments");
+  pack_dw_weight_kernel<<<(unsigned)vkas_cdiv(49L * Cp, 256), 256, 0, vkas_stream(stream)>>>(w, out, C, Cp, flip);
+  VKAS_LAUNCH_CHECK("pack_dw_weight");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_unpack_dw_wgrad(const float* gw, float* grad, int C, int Cp, int accumulate, void* stream) {
+  VKAS_CHECK(gw && grad && C > 0 && Cp >= C, "vkas_unpack_dw_wgrad: bad arguments");
+  unpack_dw_wgrad_kernel<<<(unsigned)vkas_cdiv(49L * C, 256), 256, 0, vkas_stream(stream)>>>(gw, grad, C, Cp, accumulate);
+  VKAS_LAUNCH_CHECK("unpack_dw_wgrad");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_image_nchw_to_nhwc8(const float* img, void* out, int B, int C, int H, int W, int dtype,
+                                        void* stream) {
+  VKAS_CHECK(img && out && vkas_aligned16(out), "vkas_image_nchw_to_nhwc8: null/misaligned pointer");
+  VKAS_CHECK(B >= 0 && C > 0 && C <= 8 && H > 0 && W > 0, "vkas_image_nchw_to_nhwc8: bad dims");
+  if (B == 0) return VKAS_OK;
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_image_nchw_to_nhwc8", {
+    image_to_nhwc8_kernel<T><<<grid1d((long)B * H * W), 256, 0, vkas_stream(stream)>>>(img, (T*)out, B, C, H, W);
+  })
+  VKAS_LAUNCH_CHECK("image_nchw_to_nhwc8");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_nhwc_to_nchw_f32(const void* x, long ld, float* out, int B, int H, int W, int C, int dtype,
+                                     void* stream) {
+  VKAS_CHECK(x && out && B >= 0 && H > 0 && W > 0 && C > 0 && ld >= C, "vkas_nhwc_to_nchw_f32: bad arguments");
+  if (B == 0) return VKAS_OK;
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_nhwc_to_nchw_f32", {
+    nhwc_to_nchw_kernel<T><<<grid1d((long)B * C * H * W), 256, 0, vkas_stream(stream)>>>((const T*)x, ld, out, B,
+                                                                                        (long)H * W, C);
+  })
+  VKAS_LAUNCH_CHECK("nhwc_to_nchw_f32");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_nchw_f32_to_nhwc(const float* g, void* out, long ld, int B, int H, int W, int C, int Cp, int dtype,
+                                     void* stream) {
+  VKAS_CHECK(g && out && B >= 0 && H > 0 && W > 0 && C > 0 && Cp >= C && ld >= Cp, "vkas_nchw_f32_to_nhwc: bad arguments");
+  if (B == 0) return VKAS_OK;
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_nchw_f32_to_nhwc", {
+    nchw_to_nhwc_kernel<T><<<grid1d((long)B * H * W * Cp), 256, 0, vkas_stream(stream)>>>(g, (T*)out, ld, B, (long)H * W,
+                                                                                         C, Cp);
+  })
+  VKAS_LAUNCH_CHECK("nchw_f32_to_nhwc");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_copy_channels(const void* x, long ldx, void* y, long ldy, long M, int Cp, int accumulate, int dtype,
+                                  void* stream) {
+  VKAS_CHECK(x && y && vkas_aligned16(x) && vkas_aligned16(y), "vkas_copy_channels: null/misaligned pointer");
+  VKAS_CHECK(Cp > 0 && Cp % 8 == 0 && ldx >= Cp && ldy >= Cp && ldx % 8 == 0 && ldy % 8 == 0, "vkas_copy_channels: bad strides");
+  if (M <= 0) return VKAS_OK;
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_copy_channels", {
+    copy_channels_kernel<T><<<grid1d(M * (Cp / 8)), 256, 0, vkas_stream(stream)>>>((const T*)x, ldx, (T*)y, ldy, M,
+                                                                                  Cp / 8, accumulate);
+  })
+  VKAS_LAUNCH_CHECK("copy_channels");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_softplus_fwd(const float* x, float* y, long n, void* stream) {
+  VKAS_CHECK(x && y && n >= 0, "vkas_softplus_fwd: bad arguments");
+  if (n == 0) return VKAS_OK;
+  softplus_fwd_kernel<<<grid1d(n), 256, 0, vkas_stream(stream)>>>(x, y, n);
+  VKAS_LAUNCH_CHECK("softplus_fwd");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_softplus_bwd(const float* x, const float* dy, float* dx, long n, void* stream) {
+  VKAS_CHECK(x && dy && dx && n >= 0, "vkas_softplus_bwd: bad arguments");
+  if (n == 0) return VKAS_OK;
+  softplus_bwd_kernel<<<grid1d(n), 256, 0, vkas_stream(stream)>>>(x, dy, dx, n);
+  VKAS_LAUNCH_CHECK("softplus_bwd");
+  return VKAS_OK;
+}

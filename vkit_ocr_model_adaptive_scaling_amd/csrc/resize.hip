@@ -1,0 +1,299 @@
+// F.interpolate on NHWC activations: bilinear, align_corners=False (upernext.py:79,178-195,237-244) and
+// nearest (fpn.py:125-142,197-204), plus nn.AdaptiveAvgPool2d (upernext.py:62).  All are gathers: a thread
+// owns one 8-channel vector of one destination pixel, consecutive lanes walk channels then x, so every
+// load/store is a coalesced 16-byte access.  The backward kernels are gathers too (each source pixel sums
+// the destination pixels that referenced it, enumerated from the same index function as the forward), so
+// no float atomics and bit-reproducible results.
+#include "vkas_common.h"
+
+namespace {
+
+// source coordinate of F.interpolate(bilinear, align_corners=False): src = max((dst+0.5)*in/out-0.5, 0)
+__device__ __forceinline__ void bilinear_src(int dst, float scale, int n_in, int& i0, int& i1, float& w1) {
+  float src = ((float)dst + 0.5f) * scale - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  if (i0 > n_in - 1) i0 = n_in - 1;
+  i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
+  w1 = src - (float)i0;
+}
+// nearest: src = min(floor(dst * in/out), in-1), evaluated in integers
+__device__ __forceinline__ int nearest_src(int dst, int n_in, int n_out) {
+  const int s = (int)(((long)dst * n_in) / n_out);
+  return s < n_in - 1 ? s : n_in - 1;
+}
+
+// weight with which destination index `dst` reads source index `src_i` along one axis (0 if it does not)
+__device__ __forceinline__ float axis_weight(int dst, float scale, int n_in, int n_out, int src_i, int mode) {
+  if (mode == 0) {
+    int i0, i1;
+    float w1;
+    bilinear_src(dst, scale, n_in, i0, i1, w1);
+    return (i0 == src_i ? 1.f - w1 : 0.f) + (i1 == src_i ? w1 : 0.f);
+  }
+  return nearest_src(dst, n_in, n_out) == src_i ? 1.f : 0.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void resize_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
+                                                         int B, int Hin, int Win, int Hout, int Wout, int nvec, int mode,
+                                                         int accumulate) {
+  const long total = (long)B * Hout * Wout * nvec;
+  const float sy = (float)Hin / (float)Hout, sx = (float)Win / (float)Wout;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int v = (int)(i % nvec);
+    long p = i / nvec;
+    const int ox = (int)(p % Wout);
+    p /= Wout;
+    const int oy = (int)(p % Hout);
+    const int b = (int)(p / Hout);
+    float o[8];
+    const T* xb = x + (long)b * Hin * Win * ldx + v * 8;
+    if (mode == 0) {
+      int y0, y1, x0, x1;
+      float wy, wx;
+      bilinear_src(oy, sy, Hin, y0, y1, wy);
+      bilinear_src(ox, sx, Win, x0, x1, wx);
+      float a[8], bq[8], c[8], d[8];
+      load8(xb + ((long)y0 * Win + x0) * ldx, a);
+      load8(xb + ((long)y0 * Win + x1) * ldx, bq);
+      load8(xb + ((long)y1 * Win + x0) * ldx, c);
+      load8(xb + ((long)y1 * Win + x1) * ldx, d);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float top = a[k] * (1.f - wx) + bq[k] * wx;
+        const float bot = c[k] * (1.f - wx) + d[k] * wx;
+        o[k] = top * (1.f - wy) + bot * wy;
+      }
+    } else {
+      const int iy = nearest_src(oy, Hin, Hout), ix = nearest_src(ox, Win, Wout);
+      load8(xb + ((long)iy * Win + ix) * ldx, o);
+    }
+    T* dst = y + (((long)b * Hout + oy) * Wout + ox) * ldy + v * 8;
+    if (accumulate) {
+      float t[8];
+      load8(dst, t);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] += t[k];
+    }
+    store8(dst, o);
+  }
+}
+
+// dx[b,iy,ix] (+)= sum over destination pixels (oy,ox) of weight(oy->iy) * weight(ox->ix) * dy[b,oy,ox]
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ dy, long lddy, T* __restrict__ dx,
+                                                         long lddx, int B, int Hin, int Win, int Hout, int Wout,
+                                                         int nvec, int mode, int accumulate) {
+  const long total = (long)B * Hin * Win * nvec;
+  const float sy = (float)Hin / (float)Hout, sx = (float)Win / (float)Wout;
+  const float ry = (float)Hout / (float)Hin, rx = (float)Wout / (float)Win;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int v = (int)(i % nvec);
+    long p = i / nvec;
+    const int ix = (int)(p % Win);
+    p /= Win;
+    const int iy = (int)(p % Hin);
+    const int b = (int)(p / Hin);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const T* db = dy + (long)b * Hout * Wout * lddy + v * 8;
+    // candidate destination ranges (conservative; every candidate is re-checked with the forward index function)
+    int oy_lo, oy_hi, ox_lo, ox_hi;
+    if (mode == 0) {
+      oy_lo = (int)floorf(((float)iy - 1.f) * ry) - 2;
+      oy_hi = (int)ceilf(((float)iy + 1.5f) * ry) + 2;
+      ox_lo = (int)floorf(((float)ix - 1.f) * rx) - 2;
+      ox_hi = (int)ceilf(((float)ix + 1.5f) * rx) + 2;
+    } else {
+      oy_lo = (int)floorf((float)iy * ry) - 2;
+      oy_hi = (int)ceilf(((float)iy + 1.f) * ry) + 2;
+      ox_lo = (int)floorf((float)ix * rx) - 2;
+      ox_hi = (int)ceilf(((float)ix + 1.f) * rx) + 2;
+    }
+    // the last source row/column also collects every clamped destination
+    if (iy == Hin - 1) oy_hi = Hout - 1;
+    if (ix == Win - 1) ox_hi = Wout - 1;
+    if (oy_lo < 0) oy_lo = 0;
+    if (ox_lo < 0) ox_lo = 0;
+    if (oy_hi > Hout - 1) oy_hi = Hout - 1;
+    if (ox_hi > Wout - 1) ox_hi = Wout - 1;
+    // tighten both ranges to the destinations that really reference this source pixel
+    while (oy_lo <= oy_hi && axis_weight(oy_lo, sy, Hin, Hout, iy, mode) == 0.f) ++oy_lo;
+    while (oy_hi >= oy_lo && axis_weight(oy_hi, sy, Hin, Hout, iy, mode) == 0.f) --oy_hi;
+    while (ox_lo <= ox_hi && axis_weight(ox_lo, sx, Win, Wout, ix, mode) == 0.f) ++ox_lo;
+    while (ox_hi >= ox_lo && axis_weight(ox_hi, sx, Win, Wout, ix, mode) == 0.f) --ox_hi;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      const float wyv = axis_weight(oy, sy, Hin, Hout, iy, mode);
+      if (wyv == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const float wxv = axis_weight(ox, sx, Win, Wout, ix, mode);
+        if (wxv == 0.f) continue;
+        float t[8];
+        load8(db + ((long)oy * Wout + ox) * lddy, t);
+        const float wgt = wyv * wxv;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = fmaf(wgt, t[k], acc[k]);
+      }
+    }
+    T* dst = dx + (((long)b * Hin + iy) * Win + ix) * lddx + v * 8;
+    if (accumulate) {
+      float t[8];
+      load8(dst, t);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += t[k];
+    }
+    store8(dst, acc);
+  }
+}
+
+// bin i of AdaptiveAvgPool: [floor(i*n/s), ceil((i+1)*n/s))
+__device__ __forceinline__ void pool_bin(int i, int n, int s, int& lo, int& hi) {
+  lo = (i * n) / s;
+  hi = ((i + 1) * n + s - 1) / s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
+                                                          int B, int H, int W, int s, int nvec) {
+  const long total = (long)B * s * s * nvec;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int v = (int)(i % nvec);
+    long p = i / nvec;
+    const int bj = (int)(p % s);
+    p /= s;
+    const int bi = (int)(p % s);
+    const int b = (int)(p / s);
+    int y0, y1, x0, x1;
+    pool_bin(bi, H, s, y0, y1);
+    pool_bin(bj, W, s, x0, x1);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int yy = y0; yy < y1; ++yy)
+      for (int xx = x0; xx < x1; ++xx) {
+        float t[8];
+        load8(x + (((long)b * H + yy) * W + xx) * ldx + v * 8, t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += t[k];
+      }
+    const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] *= inv;
+    store8(y + (((long)b * s + bi) * s + bj) * ldy + v * 8, acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, long lddy, T* __restrict__ dx,
+                                                          long lddx, int B, int H, int W, int s, int nvec,
+                                                          int accumulate) {
+  const long total = (long)B * H * W * nvec;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int v = (int)(i % nvec);
+    long p = i / nvec;
+    const int xx = (int)(p % W);
+    p /= W;
+    const int yy = (int)(p % H);
+    const int b = (int)(p / H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int bi = 0; bi < s; ++bi) {
+      int y0, y1;
+      pool_bin(bi, H, s, y0, y1);
+      if (yy < y0 || yy >= y1) continue;
+      for (int bj = 0; bj < s; ++bj) {
+        int x0, x1;
+        pool_bin(bj, W, s, x0, x1);
+        if (xx < x0 || xx >= x1) continue;
+        float t[8];
+        load8(dy + (((long)b * s + bi) * s + bj) * lddy + v * 8, t);
+        const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = fmaf(inv, t[k], acc[k]);
+      }
+    }
+    T* dst = dx + (((long)b * H + yy) * W + xx) * lddx + v * 8;
+    if (accumulate) {
+      float t[8];
+      load8(dst, t);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += t[k];
+    }
+    store8(dst, acc);
+  }
+}
+
+static inline unsigned grid_for(long total) {
+  long g = vkas_cdiv(total, 256);
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+static int rs_check(const char* who, const void* a, long lda, const void* b, long ldb, int B, int Hin, int Win, int Hout,
+                    int Wout, int Cp) {
+  VKAS_CHECK(a && b && vkas_aligned16(a) && vkas_aligned16(b), "%s: null/misaligned tensor", who);
+  VKAS_CHECK(B >= 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "%s: bad spatial dims", who);
+  VKAS_CHECK(Cp > 0 && Cp % 8 == 0 && lda >= Cp && ldb >= Cp && lda % 8 == 0 && ldb % 8 == 0, "%s: bad channels/strides",
+             who);
+  return VKAS_OK;
+}
+
+extern "C" int vkas_resize_fwd(const void* x, long ldx, void* y, long ldy, int B, int Hin, int Win, int Hout, int Wout,
+                               int Cp, int mode, int accumulate, int dtype, void* stream) {
+  int rc = rs_check("vkas_resize_fwd", x, ldx, y, ldy, B, Hin, Win, Hout, Wout, Cp);
+  if (rc) return rc;
+  VKAS_CHECK(mode == 0 || mode == 1, "vkas_resize_fwd: bad mode %d", mode);
+  const long total = (long)B * Hout * Wout * (Cp / 8);
+  if (total == 0) return VKAS_OK;
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_resize_fwd", {
+    resize_fwd_kernel<T><<<grid_for(total), 256, 0, vkas_stream(stream)>>>((const T*)x, ldx, (T*)y, ldy, B, Hin, Win,
+                                                                          Hout, Wout, Cp / 8, mode, accumulate);
+  })
+  VKAS_LAUNCH_CHECK("resize_fwd");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_resize_bwd(const void* dy, long lddy, void* dx, long lddx, int B, int Hin, int Win, int Hout,
+                               int Wout, int Cp, int mode, int accumulate, int dtype, void* stream) {
+  int rc = rs_check("vkas_resize_bwd", dy, lddy, dx, lddx, B, Hin, Win, Hout, Wout, Cp);
+  if (rc) return rc;
+  VKAS_CHECK(mode == 0 || mode == 1, "vkas_resize_bwd: bad mode %d", mode);
+  const long total = (long)B * Hin * Win * (Cp / 8);
+  if (total == 0) return VKAS_OK;
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_resize_bwd", {
+    resize_bwd_kernel<T><<<grid_for(total), 256, 0, vkas_stream(stream)>>>((const T*)dy, lddy, (T*)dx, lddx, B, Hin, Win,
+                                                                          Hout, Wout, Cp / 8, mode, accumulate);
+  })
+  VKAS_LAUNCH_CHECK("resize_bwd");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_adaptive_avgpool_fwd(const void* x, long ldx, void* y, long ldy, int B, int H, int W, int s, int Cp,
+                                         int dtype, void* stream) {
+  VKAS_CHECK(s > 0, "vkas_adaptive_avgpool_fwd: bad s");
+  int rc = rs_check("vkas_adaptive_avgpool_fwd", x, ldx, y, ldy, B, H, W, s, s, Cp);
+  if (rc) return rc;
+  const long total = (long)B * s * s * (Cp / 8);
+  if (total == 0) return VKAS_OK;
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_adaptive_avgpool_fwd", {
+    avgpool_fwd_kernel<T><<<grid_for(total), 256, 0, vkas_stream(stream)>>>((const T*)x, ldx, (T*)y, ldy, B, H, W, s,
+                                                                           Cp / 8);
+  })
+  VKAS_LAUNCH_CHECK("adaptive_avgpool_fwd");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_adaptive_avgpool_bwd(const void* dy, long lddy, void* dx, long lddx, int B, int H, int W, int s,
+                                         int Cp, int accumulate, int dtype, void* stream) {
+  VKAS_CHECK(s > 0, "vkas_adaptive_avgpool_bwd: bad s");
+  int rc = rs_check("vkas_adaptive_avgpool_bwd", dy, lddy, dx, lddx, B, H, W, s, s, Cp);
+  if (rc) return rc;
+  const long total = (long)B * H * W * (Cp / 8);
+  if (total == 0) return VKAS_OK;
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_adaptive_avgpool_bwd", {
+    avgpool_bwd_kernel<T><<<grid_for(total), 256, 0, vkas_stream(stream)>>>((const T*)dy, lddy, (T*)dx, lddx, B, H, W, s,
+                                                                           Cp / 8, accumulate);
+  })
+  VKAS_LAUNCH_CHECK("adaptive_avgpool_bwd");
+  return VKAS_OK;
+}

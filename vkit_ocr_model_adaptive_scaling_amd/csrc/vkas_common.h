@@ -1,0 +1,116 @@
+// Shared host/device helpers for libvkas (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <math.h>
+
+#include "../../include/vkas.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+void vkas_set_error(const char* fmt, ...);
+
+#define VKAS_CHECK(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      vkas_set_error(__VA_ARGS__);       \
+      return VKAS_E_ARG;                 \
+    }                                    \
+  } while (0)
+
+#define VKAS_LAUNCH_CHECK(name)                                              \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess) {                                                 \
+      vkas_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return VKAS_E_LAUNCH;                                                  \
+    }                                                                        \
+  } while (0)
+
+#define VKAS_DISPATCH_DTYPE(dtype, NAME, ...)                  \
+  if ((dtype) == VKAS_F32) {                                   \
+    using T = float;                                           \
+    __VA_ARGS__                                                \
+  } else if ((dtype) == VKAS_BF16) {                           \
+    using T = bf16_t;                                          \
+    __VA_ARGS__                                                \
+  } else {                                                     \
+    vkas_set_error("%s: unknown dtype %d", NAME, (int)(dtype)); \
+    return VKAS_E_ARG;                                         \
+  }
+
+static inline bool vkas_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+static inline hipStream_t vkas_stream(void* s) { return (hipStream_t)s; }
+static inline long vkas_cdiv(long a, long b) { return (a + b - 1) / b; }
+
+// ---- device helpers -------------------------------------------------------------------------------
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// 8 consecutive elements <-> 8 floats.  Pointers must be 16-byte aligned (8-element granularity).
+__device__ __forceinline__ void load8(const float* p, float* v) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float* v) {
+  const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+__device__ __forceinline__ void store8(float* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float* v) {
+  bf16x8 a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+  *reinterpret_cast<bf16x8*>(p) = a;
+}
+__device__ __forceinline__ void load4(const float* p, float* v) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float* v) {
+  const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
+}
+__device__ __forceinline__ void store4(float* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store4(bf16_t* p, const float* v) {
+  bf16x4 a;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = (bf16_t)v[i];
+  *reinterpret_cast<bf16x4*>(p) = a;
+}
+
+// exact (erf) GELU and its derivative: helper.py:100-101
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

@@ -1,0 +1,140 @@
+"""AdaptiveScaling model assembly (mirror of vkit_open_model/model/adaptive_scaling.py) on the HIP ops."""
+import logging
+from enum import Enum, unique
+from typing import Dict, Mapping, Optional, Sequence, Tuple
+
+import attrs
+import torch
+from torch import nn
+
+from .convnext import ConvNext
+from .fpn import FpnNeck, FpnHead
+from .upernext import UperNextNeck, UperNextHead
+from .helper import set_compute_dtype
+from .. import ops
+
+logger = logging.getLogger(__name__)
+
+
+@unique
+class AdaptiveScalingSize(Enum):
+    TINY = 'tiny'
+    SMALL = 'small'
+    BASE = 'base'
+    LARGE = 'large'
+
+
+@unique
+class AdaptiveScalingNeckHeadType(Enum):
+    FPN = 'fpn'
+    UPERNEXT = 'upernext'
+
+
+@attrs.define
+class AdaptiveScalingConfig:
+    """adaptive_scaling.py:41-48 (same fields, same defaults)."""
+    size: AdaptiveScalingSize = AdaptiveScalingSize.SMALL
+    neck_head_type: AdaptiveScalingNeckHeadType = AdaptiveScalingNeckHeadType.FPN
+    rough_upsampling_factor: int = 2
+    rough_init_char_height_output_bias: float = 8.0
+    precise_upsampling_factor: int = 2
+    precise_enable_char_mask_head: bool = False
+
+
+class _SoftplusSlot(nn.Module):
+    """Occupies index 1 of the Softplus-wrapped heads (adaptive_scaling.py:93-102,133-141); applied via ops.Softplus."""
+
+    def forward(self, x):
+        return ops.Softplus.apply(x)
+
+
+_BACKBONES = {
+    AdaptiveScalingSize.TINY: ConvNext.create_tiny,
+    AdaptiveScalingSize.SMALL: ConvNext.create_small,
+    AdaptiveScalingSize.BASE: ConvNext.create_base,
+    AdaptiveScalingSize.LARGE: ConvNext.create_large,
+}
+
+
+class AdaptiveScaling(nn.Module):
+
+    def __init__(self, config: AdaptiveScalingConfig, compute_dtype: torch.dtype = torch.bfloat16):
+        super().__init__()
+        if config.size not in _BACKBONES:
+            raise NotImplementedError()
+        self.backbone = _BACKBONES[config.size]()
+        if config.neck_head_type == AdaptiveScalingNeckHeadType.FPN:
+            neck_cls, head_cls = FpnNeck, FpnHead
+        elif config.neck_head_type == AdaptiveScalingNeckHeadType.UPERNEXT:
+            neck_cls, head_cls = UperNextNeck, UperNextHead
+        else:
+            raise NotImplementedError()
+        width = self.backbone.in_channels_group[-2]  # adaptive_scaling.py:79
+
+        def head(out_channels, factor, bias=0.0):
+            return head_cls(in_channels=width, out_channels=out_channels, upsampling_factor=factor,
+                            init_output_bias=bias)
+
+        rf, pf = config.rough_upsampling_factor, config.precise_upsampling_factor
+        self.rough_neck = neck_cls(in_channels_group=self.backbone.in_channels_group, out_channels=width)
+        self.rough_char_mask_head = head(1, rf)
+        self.rough_char_height_head = nn.Sequential(head(1, rf, config.rough_init_char_height_output_bias),
+                                                    _SoftplusSlot())
+        self.precise_neck = neck_cls(in_channels_group=self.backbone.in_channels_group, out_channels=width)
+        self.precise_char_mask_head = head(1, pf) if config.precise_enable_char_mask_head else None
+        self.precise_char_prob_head = head(1, pf)
+        self.precise_char_up_left_corner_offset_head = head(2, pf)
+        self.precise_char_corner_angle_head = head(4, pf)
+        self.precise_char_corner_distance_head = nn.Sequential(head(4, pf), _SoftplusSlot())
+        set_compute_dtype(self, compute_dtype)
+
+    def set_compute_dtype(self, dtype: torch.dtype):
+        return set_compute_dtype(self, dtype)
+
+    def _run_heads(self, neck_feature: torch.Tensor, heads: Sequence[nn.Module]):
+        # every head of a pass reads the same neck feature: upsample it once (adaptive_scaling.py:150-152,163-170)
+        first = heads[0][0] if isinstance(heads[0], nn.Sequential) else heads[0]
+        up = first.upsample_act(neck_feature)
+        outs = []
+        for h in heads:
+            if isinstance(h, nn.Sequential):
+                outs.append(h[1](h[0].forward_act(neck_feature, upsampled=up)))
+            else:
+                outs.append(h.forward_act(neck_feature, upsampled=up))
+        return tuple(outs)
+
+    def forward_rough(self, x: torch.Tensor, drop_masks=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """adaptive_scaling.py:143-154"""
+        feats = self.backbone.forward_act(x, drop_masks)
+        neck = self.rough_neck.forward_act(feats)
+        return self._run_heads(neck, (self.rough_char_mask_head, self.rough_char_height_head))  # type: ignore
+
+    def forward_precise(self, x: torch.Tensor, drop_masks=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """adaptive_scaling.py:156-177"""
+        feats = self.backbone.forward_act(x, drop_masks)
+        neck = self.precise_neck.forward_act(feats)
+        return self._run_heads(neck, (self.precise_char_prob_head, self.precise_char_up_left_corner_offset_head,
+                                      self.precise_char_corner_angle_head,
+                                      self.precise_char_corner_distance_head))  # type: ignore
+
+    # ---- gradient inspection helpers (adaptive_scaling.py:179-237) ---------------------------------------
+    @classmethod
+    def debug_get_rough_name_to_grad(cls, model: nn.Module) -> Dict[str, torch.Tensor]:
+        return {n: p.grad.cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    @classmethod
+    def debug_get_precise_name_to_grad(cls, model: nn.Module, rough_name_to_grad: Mapping[str, torch.Tensor]):
+        return {n: p.grad.cpu() - rough_name_to_grad[n] for n, p in model.named_parameters()
+                if p.grad is not None and n in rough_name_to_grad}
+
+    @classmethod
+    def debug_inspect_name_to_grad(cls, rough_name_to_grad: Mapping[str, torch.Tensor],
+                                   precise_name_to_grad: Mapping[str, torch.Tensor]):
+        names = sorted(set(rough_name_to_grad) & set(precise_name_to_grad))
+        stats = {}
+        for tag, table in (('rough', rough_name_to_grad), ('precise', precise_name_to_grad)):
+            g = torch.abs(torch.cat([table[n].reshape(-1) for n in names]))
+            stats[tag] = (float(g.mean()), float(g.std()))
+            logger.info(f'{tag}_abs_grads_mean = {stats[tag][0]}, {tag}_abs_grads_std = {stats[tag][1]}')
+        logger.info(f'rough_abs_grads_mean / precise_abs_grads_mean = {stats["rough"][0] / (stats["precise"][0] + 1E-15)}')
+        return stats

@@ -1,0 +1,110 @@
+"""FPN neck / head (mirror of vkit_open_model/model/fpn.py) on the HIP ops."""
+from typing import List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from . import helper
+from .. import ops
+
+NEAREST = 1
+
+
+def build_conv1x1_block(in_channels: int, out_channels: int):
+    """fpn.py:21-28"""
+    return nn.Sequential(helper.permute_bchw_to_bhwc(), helper.conv1x1(in_channels, out_channels),
+                         helper.ln(out_channels), helper.permute_bhwc_to_bchw(), helper.gelu())
+
+
+def build_conv3x3_block(in_channels: int, out_channels: int):
+    """fpn.py:31-38"""
+    return nn.Sequential(helper.conv3x3(in_channels, out_channels), helper.permute_bchw_to_bhwc(),
+                         helper.ln(out_channels), helper.permute_bhwc_to_bchw(), helper.gelu())
+
+
+def _init_kaiming(module: nn.Module):
+    for m in module.modules():  # fpn.py:104-108,185-189
+        if isinstance(m, (nn.Conv2d, nn.Linear)):
+            nn.init.kaiming_normal_(m.weight)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+
+
+class FpnNeck(nn.Module):
+    """fpn.py:51-146: 1x1 laterals to out_channels, top-down nearest add, 3x3 blocks to out/levels, nearest to
+    level 0, concat."""
+
+    @classmethod
+    def build_step1_conv_blocks(cls, in_channels_group: Sequence[int], out_channels: int):
+        return nn.ModuleList([build_conv1x1_block(c, out_channels) for c in in_channels_group])
+
+    @classmethod
+    def build_step2_conv_blocks(cls, in_channels_group: Sequence[int], out_channels: int):
+        assert out_channels % len(in_channels_group) == 0
+        inner = out_channels // len(in_channels_group)
+        return nn.ModuleList([build_conv3x3_block(out_channels, inner) for _ in in_channels_group])
+
+    def __init__(self, in_channels_group: Sequence[int], out_channels: int) -> None:
+        super().__init__()
+        assert len(in_channels_group) > 1
+        if out_channels % (8 * len(in_channels_group)) != 0:
+            raise NotImplementedError('HIP neck needs out_channels / levels to be a multiple of 8')
+        self.out_channels = out_channels
+        self.step1_conv_blocks = self.build_step1_conv_blocks(in_channels_group, out_channels)
+        self.step2_conv_blocks = self.build_step2_conv_blocks(in_channels_group, out_channels)
+        self.compute_dtype = torch.bfloat16
+        _init_kaiming(self)
+
+    def forward_act(self, feats: Sequence[torch.Tensor]) -> torch.Tensor:
+        n = len(feats)
+        assert n == len(self.step1_conv_blocks)
+        outs = [helper.conv_block(feats[i], blk[1], blk[2]) for i, blk in enumerate(self.step1_conv_blocks)]
+        for i in range(n - 1, 0, -1):
+            outs[i - 1] = ops.ResizeAdd.apply(outs[i - 1], outs[i], NEAREST)
+        outs = [helper.conv_block(o, blk[0], blk[2], 1, 1) for o, blk in zip(outs, self.step2_conv_blocks)]
+        size0 = (feats[0].shape[1], feats[0].shape[2])
+        for i in range(1, n):
+            outs[i] = ops.Resize.apply(outs[i], size0, NEAREST)
+        return ops.Cat.apply(*outs)
+
+    def forward(self, features: List[torch.Tensor]) -> torch.Tensor:  # type: ignore
+        acts = [helper.nchw_to_act(f, self.compute_dtype) for f in features]
+        return helper.act_to_nchw(self.forward_act(acts), self.out_channels)
+
+
+class FpnHead(nn.Module):
+    """fpn.py:149-208"""
+
+    def __init__(self, in_channels: int, out_channels: int, upsampling_factor: int = 1,
+                 init_output_bias: float = 0.0):
+        super().__init__()
+        self.upsampling_factor = upsampling_factor
+        self.out_channels = out_channels
+        inner_channels = (in_channels + out_channels) // 2
+        if 1 <= upsampling_factor <= 2:
+            self.step1_conv = build_conv3x3_block(in_channels, inner_channels)
+        else:
+            # fpn.py:170-176: 5x5 smoothing for factors in (2, 4] is unreachable at the reference's defaults
+            # (adaptive_scaling.py:45,47) and has no HIP kernel.
+            raise NotImplementedError()
+        self.step2_conv = nn.Sequential(helper.permute_bchw_to_bhwc(), helper.conv1x1(inner_channels, out_channels),
+                                        helper.permute_bhwc_to_bchw())
+        self.compute_dtype = torch.bfloat16
+        _init_kaiming(self)
+        nn.init.constant_(self.step2_conv[1].bias, init_output_bias)  # fpn.py:191
+
+    def upsample_act(self, x: torch.Tensor) -> torch.Tensor:
+        if self.upsampling_factor > 1:
+            f = self.upsampling_factor
+            return ops.Resize.apply(x, (x.shape[1] * f, x.shape[2] * f), NEAREST)
+        return x
+
+    def forward_act(self, x: torch.Tensor, upsampled: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = self.upsample_act(x) if upsampled is None else upsampled
+        x = helper.conv_block(x, self.step1_conv[0], self.step1_conv[2], 1, 1)
+        proj = self.step2_conv[1]
+        y = ops.Conv.apply(x, proj.weight, proj.bias, 1, 0)
+        return ops.ToNchw.apply(y, self.out_channels)
+
+    def forward(self, fpn_neck_feature: torch.Tensor) -> torch.Tensor:  # type: ignore
+        return self.forward_act(helper.nchw_to_act(fpn_neck_feature, self.compute_dtype))

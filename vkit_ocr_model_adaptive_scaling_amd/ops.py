@@ -1,0 +1,607 @@
+"""Autograd ops of the adaptive-scaling hot path, backed by libvkas.so (HIP, gfx950).
+
+Activations travel between ops as NHWC tensors of shape (B, H, W, Cp) in the compute dtype (bf16 or
+fp32), Cp = channels rounded up to a multiple of 8 with zero pad channels; a channel slice of a wider
+tensor (pixel stride ld > Cp) is accepted everywhere, which is how concatenation stays copy-free on
+the consumer side.  Parameters stay fp32 in the reference's own layouts; each op converts what it
+needs with the pack kernels.  Every op launches on torch's current HIP stream and allocates through
+torch's caching allocator; nothing here falls back to torch math or to the CPU.
+"""
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import lib, check, ConvGeom, Epilogue
+
+_FLOAT = torch.float32
+
+
+def rup8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return _lib.BF16
+    if t.dtype == torch.float32:
+        return _lib.F32
+    raise TypeError(f'unsupported activation dtype {t.dtype}')
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('vkas ops run on the MI355X only (tensor is on %s); there is no CPU fallback' % t.device)
+
+
+def act_ok(t: torch.Tensor) -> bool:
+    if t.dim() != 4 or t.shape[3] % 8 != 0:
+        return False
+    B, H, W, C = t.shape
+    ld = t.stride(2) if W > 1 else (t.stride(1) if H > 1 else (t.stride(0) if B > 1 else C))
+    if t.stride(3) != 1 and C > 1:
+        return False
+    if ld < C or ld % 8 != 0 or t.data_ptr() % 16 != 0:
+        return False
+    if W > 1 and t.stride(2) != ld:
+        return False
+    if H > 1 and t.stride(1) != W * ld:
+        return False
+    if B > 1 and t.stride(0) != H * W * ld:
+        return False
+    return True
+
+
+def act_ld(t: torch.Tensor) -> int:
+    B, H, W, C = t.shape
+    if W > 1:
+        return t.stride(2)
+    if H > 1:
+        return t.stride(1)
+    if B > 1:
+        return t.stride(0)
+    return C
+
+
+def as_act(t: torch.Tensor) -> torch.Tensor:
+    """Return t if it is a valid (possibly channel-sliced) NHWC activation, else a dense copy."""
+    return t if act_ok(t) else t.contiguous()
+
+
+def new_act(B, H, W, Cp, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty((B, H, W, Cp), dtype=like.dtype, device=like.device)
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(((nbytes + 3) // 4 + 4,), dtype=_FLOAT, device=device)
+
+
+# ---------------------------------------------------------------------------------------- raw wrappers
+def pack_conv_weight(w: torch.Tensor, Np: int, Cp: int, mode: int, dtype: torch.dtype) -> torch.Tensor:
+    w4 = w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
+    N, C, KH, KW = w4.shape
+    out = torch.empty((Np * KH * KW * Cp,), dtype=dtype, device=w.device)
+    check(lib.vkas_pack_conv_weight(_p(w4.contiguous()), _p(out), N, C, KH, KW, Np, Cp, mode,
+                                    _lib.BF16 if dtype == torch.bfloat16 else _lib.F32, _stream()), 'pack_conv_weight')
+    return out
+
+
+def pad_vector(v: Optional[torch.Tensor], npad: int) -> Optional[torch.Tensor]:
+    if v is None:
+        return None
+    v = v.reshape(-1)
+    if v.numel() == npad and v.is_contiguous():
+        return v
+    out = torch.empty((npad,), dtype=_FLOAT, device=v.device)
+    check(lib.vkas_pad_vector(_p(v.contiguous()), _p(out), v.numel(), npad, _stream()), 'pad_vector')
+    return out
+
+
+def _geom(B, Hin, Win, Hout, Wout, Cp, ldx, KH, KW, stride, pad) -> ConvGeom:
+    return ConvGeom(B, Hin, Win, Hout, Wout, Cp, ldx, KH, KW, stride, pad)
+
+
+def conv_gemm(x: torch.Tensor, geom: ConvGeom, Bw: torch.Tensor, Np: int, out: torch.Tensor, mode=_lib.EPI_NONE,
+              bias=None, out2=None, aux=None, colscale=None, rowscale=None, rows_per_image=0, patch=0, patch_hw=(0, 0),
+              patch_Cp=0):
+    epi = Epilogue(mode, _p(bias).value if bias is not None else None, out.data_ptr(), act_ld(out),
+                   out2.data_ptr() if out2 is not None else None, act_ld(out2) if out2 is not None else 0,
+                   aux.data_ptr() if aux is not None else None, act_ld(aux) if aux is not None else 0,
+                   colscale.data_ptr() if colscale is not None else None,
+                   rowscale.data_ptr() if rowscale is not None else None, rows_per_image, patch, patch_hw[0],
+                   patch_hw[1], patch_Cp)
+    check(lib.vkas_conv_gemm_fwd(_p(x), ctypes.byref(geom), _p(Bw), Np, ctypes.byref(epi), _dt(x), _stream()),
+          'conv_gemm_fwd')
+    return out
+
+
+def conv_wgrad(x: torch.Tensor, geom: ConvGeom, dy: torch.Tensor, Np: int) -> torch.Tensor:
+    K = geom.KH * geom.KW * geom.Cp
+    gw = torch.zeros((Np * K,), dtype=_FLOAT, device=x.device)
+    check(lib.vkas_conv_gemm_wgrad(_p(x), ctypes.byref(geom), _p(dy), act_ld(dy), Np, _p(gw), _dt(x), _stream()),
+          'conv_gemm_wgrad')
+    return gw
+
+
+def unpack_wgrad(gw: torch.Tensor, shape4, Np: int, Cp: int) -> torch.Tensor:
+    N, C, KH, KW = shape4
+    g = torch.empty((N, C, KH, KW), dtype=_FLOAT, device=gw.device)
+    check(lib.vkas_unpack_conv_wgrad(_p(gw), _p(g), N, C, KH, KW, Np, Cp, 0, _stream()), 'unpack_conv_wgrad')
+    return g
+
+
+def colsum(y: torch.Tensor, n_logical: int) -> torch.Tensor:
+    B, H, W, Np = y.shape
+    M = B * H * W
+    out = torch.empty((Np,), dtype=_FLOAT, device=y.device)
+    nbytes = lib.vkas_colsum_ws_bytes(M, Np)
+    ws = _ws(nbytes, y.device)
+    check(lib.vkas_colsum(_p(y), act_ld(y), M, Np, _p(out), 0, _p(ws), nbytes, _dt(y), _stream()), 'colsum')
+    return out[:n_logical]
+
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, C: int, act_gelu: bool,
+                  out: Optional[torch.Tensor] = None):
+    B, H, W, Cp = x.shape
+    M = B * H * W
+    y = new_act(B, H, W, Cp, x) if out is None else out
+    stats = torch.empty((M, 2), dtype=_FLOAT, device=x.device)
+    check(lib.vkas_layernorm_fwd(_p(x), act_ld(x), _p(gamma), _p(beta), _p(y), act_ld(y), _p(stats), M, C, Cp,
+                                 int(act_gelu), _dt(x), _stream()), 'layernorm_fwd')
+    return y, stats
+
+
+def layernorm_bwd(x, gamma, beta, stats, dy, C: int, act_gelu: bool):
+    B, H, W, Cp = x.shape
+    M = B * H * W
+    dx = new_act(B, H, W, Cp, x)
+    dg = torch.empty((Cp,), dtype=_FLOAT, device=x.device)
+    db = torch.empty((Cp,), dtype=_FLOAT, device=x.device)
+    nbytes = lib.vkas_layernorm_bwd_ws_bytes(M, Cp)
+    ws = _ws(nbytes, x.device)
+    check(lib.vkas_layernorm_bwd(_p(x), act_ld(x), _p(gamma), _p(beta), _p(stats), _p(dy), act_ld(dy), _p(dx),
+                                 act_ld(dx), _p(dg), _p(db), _p(ws), nbytes, M, C, Cp, int(act_gelu), _dt(x),
+                                 _stream()), 'layernorm_bwd')
+    return dx, dg[:C], db[:C]
+
+
+def resize_fwd(x, size: Tuple[int, int], mode: int, out=None, accumulate=False):
+    B, Hin, Win, Cp = x.shape
+    Hout, Wout = size
+    y = new_act(B, Hout, Wout, Cp, x) if out is None else out
+    check(lib.vkas_resize_fwd(_p(x), act_ld(x), _p(y), act_ld(y), B, Hin, Win, Hout, Wout, Cp, mode, int(accumulate),
+                              _dt(x), _stream()), 'resize_fwd')
+    return y
+
+
+def resize_bwd(dy, in_size: Tuple[int, int], mode: int):
+    B, Hout, Wout, Cp = dy.shape
+    Hin, Win = in_size
+    dx = new_act(B, Hin, Win, Cp, dy)
+    check(lib.vkas_resize_bwd(_p(dy), act_ld(dy), _p(dx), act_ld(dx), B, Hin, Win, Hout, Wout, Cp, mode, 0, _dt(dy),
+                              _stream()), 'resize_bwd')
+    return dx
+
+
+def copy_channels(x, out, accumulate=False):
+    B, H, W, Cp = x.shape
+    check(lib.vkas_copy_channels(_p(x), act_ld(x), _p(out), act_ld(out), B * H * W, Cp, int(accumulate), _dt(x),
+                                 _stream()), 'copy_channels')
+    return out
+
+
+# ---------------------------------------------------------------------------------------- autograd ops
+class ImageToAct(Function):
+    """(B,3,H,W) fp32 NCHW raw pixels -> (B,H,W,8) activation (channels 3..7 zero).  No gradient: the model
+    input is data (train.py:399-403)."""
+
+    @staticmethod
+    def forward(ctx, img: torch.Tensor, dtype: torch.dtype):
+        _require_cuda(img)
+        if img.dtype != _FLOAT:
+            img = img.float()
+        img = img.contiguous()
+        B, C, H, W = img.shape
+        out = torch.empty((B, H, W, 8), dtype=dtype, device=img.device)
+        check(lib.vkas_image_nchw_to_nhwc8(_p(img), _p(out), B, C, H, W,
+                                           _lib.BF16 if dtype == torch.bfloat16 else _lib.F32, _stream()),
+              'image_nchw_to_nhwc8')
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, None
+
+
+class Conv(Function):
+    """helper.conv1x1 / conv3x3 / pconv2x2 / pconv4x4 (model/helper.py:18-58) as one implicit GEMM.
+
+    x (B,Hin,Win,Cp) activation; weight in the reference layout (N,C,KH,KW) or (N,C); bias (N,) or None.
+    Only stride-1 'same' convs (pad = (K-1)/2) and non-overlapping patch convs (stride = K, pad 0) exist on
+    this path."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride: int, pad: int, need_input_grad: bool = True):
+        _require_cuda(x, weight)
+        x = as_act(x)
+        w4 = weight if weight.dim() == 4 else weight.view(weight.shape[0], weight.shape[1], 1, 1)
+        N, C, KH, KW = w4.shape
+        B, Hin, Win, Cp = x.shape
+        if Cp != rup8(C):
+            raise ValueError(f'Conv: activation has {Cp} (padded) channels, weight expects {C}')
+        Hout = (Hin + 2 * pad - KH) // stride + 1
+        Wout = (Win + 2 * pad - KW) // stride + 1
+        Np = rup8(N)
+        Bw = pack_conv_weight(w4, Np, Cp, 0, x.dtype)
+        out = new_act(B, Hout, Wout, Np, x)
+        geom = _geom(B, Hin, Win, Hout, Wout, Cp, act_ld(x), KH, KW, stride, pad)
+        conv_gemm(x, geom, Bw, Np, out, _lib.EPI_NONE, bias=pad_vector(bias, Np))
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad, bias is not None, need_input_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad, has_bias, need_input_grad = ctx.cfg
+        dy = as_act(dy)
+        w4 = weight if weight.dim() == 4 else weight.view(weight.shape[0], weight.shape[1], 1, 1)
+        N, C, KH, KW = w4.shape
+        B, Hin, Win, Cp = x.shape
+        _, Hout, Wout, Np = dy.shape
+        geom = _geom(B, Hin, Win, Hout, Wout, Cp, act_ld(x), KH, KW, stride, pad)
+        gw = unpack_wgrad(conv_wgrad(x, geom, dy, Np), (N, C, KH, KW), Np, Cp).view(weight.shape)
+        gb = colsum(dy, N) if has_bias else None
+        dx = None
+        if need_input_grad and ctx.needs_input_grad[0]:
+            if stride == 1:
+                # dgrad = same-size conv of dy with the 180-degree rotated, in/out swapped kernel
+                Bt = pack_conv_weight(w4, Np, Cp, 1, x.dtype)
+                dx = new_act(B, Hin, Win, Cp, x)
+                g2 = _geom(B, Hout, Wout, Hin, Win, Np, act_ld(dy), KH, KW, 1, KH - 1 - pad)
+                conv_gemm(dy, g2, Bt, Cp, dx, _lib.EPI_NONE)
+            else:
+                assert stride == KH == KW and pad == 0
+                Bt = pack_conv_weight(w4, Np, Cp, 2, x.dtype)
+                full = (Hout * stride == Hin and Wout * stride == Win)
+                dx = new_act(B, Hin, Win, Cp, x) if full else torch.zeros_like(x, memory_format=torch.contiguous_format)
+                g2 = _geom(B, Hout, Wout, Hout, Wout, Np, act_ld(dy), 1, 1, 1, 0)
+                conv_gemm(dy, g2, Bt, KH * KW * Cp, dx, _lib.EPI_PATCH, patch=KH, patch_hw=(Hout, Wout), patch_Cp=Cp)
+        return dx, gw, gb, None, None, None
+
+
+class LayerNorm(Function):
+    """helper.ln (+ helper.gelu) on an NHWC activation: model/helper.py:96-101."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, act_gelu: bool):
+        _require_cuda(x, gamma)
+        x = as_act(x)
+        C = gamma.numel()
+        y, stats = layernorm_fwd(x, gamma.contiguous(), beta.contiguous(), C, act_gelu)
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.act_gelu = act_gelu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        dx, dg, db = layernorm_bwd(x, gamma.contiguous(), beta.contiguous(), stats, as_act(dy), gamma.numel(),
+                                   ctx.act_gelu)
+        return dx, dg, db, None
+
+
+class ConvNextLayer(Function):
+    """ConvNextBlockLayer.forward (model/convnext.py:29-59) as five kernels:
+    dw7x7 -> LN -> GEMM(C,4C)+GELU -> GEMM(4C,C) with the layer-scale / stochastic-depth / residual epilogue.
+    ``rowscale`` is the per-sample keep mask already divided by the keep probability (:41-53) or None."""
+
+    @staticmethod
+    def forward(ctx, x, dw_w, dw_b, ln_g, ln_b, w1, b1, w2, b2, block_scale, rowscale):
+        _require_cuda(x, dw_w)
+        x = as_act(x)
+        B, H, W, Cp = x.shape
+        C = dw_w.shape[0]
+        M = B * H * W
+        dt, st = _dt(x), _stream()
+        # depthwise 7x7
+        wdw = torch.empty((49 * Cp,), dtype=_FLOAT, device=x.device)
+        check(lib.vkas_pack_dw_weight(_p(dw_w.contiguous()), _p(wdw), C, Cp, 0, st), 'pack_dw_weight')
+        y = new_act(B, H, W, Cp, x)
+        check(lib.vkas_dwconv7x7_fwd(_p(x), act_ld(x), _p(wdw), _p(pad_vector(dw_b, Cp)), None, 0, _p(y), Cp, B, H, W,
+                                     Cp, dt, st), 'dwconv7x7_fwd')
+        # LayerNorm
+        yn, stats = layernorm_fwd(y, ln_g.contiguous(), ln_b.contiguous(), C, False)
+        # MLP
+        C4 = w1.shape[0]
+        C4p = rup8(C4)
+        h = new_act(B, H, W, C4p, x)
+        g = new_act(B, H, W, C4p, x)
+        g1 = _geom(B, H, W, H, W, Cp, Cp, 1, 1, 1, 0)
+        conv_gemm(yn, g1, pack_conv_weight(w1, C4p, Cp, 0, x.dtype), C4p, h, _lib.EPI_GELU, bias=pad_vector(b1, C4p),
+                  out2=g)
+        out = new_act(B, H, W, Cp, x)
+        z = new_act(B, H, W, Cp, x)
+        g2 = _geom(B, H, W, H, W, C4p, C4p, 1, 1, 1, 0)
+        cs = pad_vector(block_scale, Cp)
+        rs = None if rowscale is None else rowscale.to(_FLOAT).contiguous()
+        conv_gemm(g, g2, pack_conv_weight(w2, Cp, C4p, 0, x.dtype), Cp, out, _lib.EPI_SCALE_RES, bias=pad_vector(b2, Cp),
+                  out2=z, aux=x, colscale=cs, rowscale=rs, rows_per_image=H * W)
+        ctx.save_for_backward(x, y, stats, yn, h, g, z, dw_w, ln_g, ln_b, w1, w2, block_scale,
+                              rs if rs is not None else torch.empty(0, device=x.device))
+        ctx.has_rs = rs is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, stats, yn, h, g, z, dw_w, ln_g, ln_b, w1, w2, block_scale, rs = ctx.saved_tensors
+        rs = rs if ctx.has_rs else None
+        dout = as_act(dout)
+        B, H, W, Cp = x.shape
+        C = dw_w.shape[0]
+        C4 = w1.shape[0]
+        C4p = rup8(C4)
+        M = B * H * W
+        dt, st, dev = _dt(x), _stream(), x.device
+        cs = pad_vector(block_scale, Cp)
+        # out = x + rs*cs*z  ->  dz, d(block_scale), d(b2)
+        dz = new_act(B, H, W, Cp, x)
+        dscale = torch.empty((Cp,), dtype=_FLOAT, device=dev)
+        db2 = torch.empty((Cp,), dtype=_FLOAT, device=dev)
+        nbytes = lib.vkas_scale_res_bwd_ws_bytes(M, Cp)
+        ws = _ws(nbytes, dev)
+        check(lib.vkas_scale_res_bwd(_p(dout), act_ld(dout), _p(z), Cp, _p(cs), _p(rs), H * W, _p(dz), Cp, _p(dscale),
+                                     _p(db2), _p(ws), nbytes, M, Cp, dt, st), 'scale_res_bwd')
+        # GEMM2: z = g W2^T + b2
+        g2 = _geom(B, H, W, H, W, C4p, C4p, 1, 1, 1, 0)
+        gw2 = unpack_wgrad(conv_wgrad(g, g2, dz, Cp), (C, C4, 1, 1), Cp, C4p).view(w2.shape)
+        dh = new_act(B, H, W, C4p, x)
+        gd = _geom(B, H, W, H, W, Cp, Cp, 1, 1, 1, 0)
+        conv_gemm(dz, gd, pack_conv_weight(w2, Cp, C4p, 1, x.dtype), C4p, dh, _lib.EPI_DGELU, aux=h)
+        # GEMM1: h = yn W1^T + b1
+        db1 = colsum(dh, C4)
+        g1 = _geom(B, H, W, H, W, Cp, Cp, 1, 1, 1, 0)
+        gw1 = unpack_wgrad(conv_wgrad(yn, g1, dh, C4p), (C4, C, 1, 1), C4p, Cp).view(w1.shape)
+        dyn = new_act(B, H, W, Cp, x)
+        gd1 = _geom(B, H, W, H, W, C4p, C4p, 1, 1, 1, 0)
+        conv_gemm(dh, gd1, pack_conv_weight(w1, C4p, Cp, 1, x.dtype), Cp, dyn, _lib.EPI_NONE)
+        # LayerNorm
+        dy, dlg, dlb = layernorm_bwd(y, ln_g.contiguous(), ln_b.contiguous(), stats, dyn, C, False)
+        # depthwise: wgrad, then dgrad (+ the residual path) in one kernel
+        gdw = torch.empty((49 * Cp,), dtype=_FLOAT, device=dev)
+        gdb = torch.empty((Cp,), dtype=_FLOAT, device=dev)
+        nbytes = lib.vkas_dwconv7x7_wgrad_ws_bytes(B, H, W, Cp)
+        ws = _ws(nbytes, dev)
+        check(lib.vkas_dwconv7x7_wgrad(_p(x), act_ld(x), _p(dy), Cp, _p(gdw), _p(gdb), _p(ws), nbytes, B, H, W, Cp, dt,
+                                       st), 'dwconv7x7_wgrad')
+        gdw_ref = torch.empty((C, 1, 7, 7), dtype=_FLOAT, device=dev)
+        check(lib.vkas_unpack_dw_wgrad(_p(gdw), _p(gdw_ref), C, Cp, 0, st), 'unpack_dw_wgrad')
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wflip = torch.empty((49 * Cp,), dtype=_FLOAT, device=dev)
+            check(lib.vkas_pack_dw_weight(_p(dw_w.contiguous()), _p(wflip), C, Cp, 1, st), 'pack_dw_weight')
+            dx = new_act(B, H, W, Cp, x)
+            check(lib.vkas_dwconv7x7_fwd(_p(dy), Cp, _p(wflip), None, _p(dout), act_ld(dout), _p(dx), Cp, B, H, W, Cp,
+                                         dt, st), 'dwconv7x7_dgrad')
+        return (dx, gdw_ref, gdb[:C], dlg, dlb, gw1, db1, gw2, db2[:C], dscale[:C].view(block_scale.shape), None)
+
+
+class Resize(Function):
+    """F.interpolate to an explicit size; mode 0 bilinear/align_corners=False (model/upernext.py:79,191-195,237-244),
+    mode 1 nearest (model/fpn.py:138-142,197-204)."""
+
+    @staticmethod
+    def forward(ctx, x, size, mode: int):
+        _require_cuda(x)
+        x = as_act(x)
+        ctx.in_size = (x.shape[1], x.shape[2])
+        ctx.mode = mode
+        return resize_fwd(x, tuple(size), mode)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return resize_bwd(as_act(dy), ctx.in_size, ctx.mode), None, None
+
+
+class ResizeAdd(Function):
+    """dst += F.interpolate(src, dst.shape) in place (model/upernext.py:174-182, model/fpn.py:121-129).  Legal for
+    the same reason as in the reference: the producer of dst saved its input, not its output."""
+
+    @staticmethod
+    def forward(ctx, dst, src, mode: int):
+        _require_cuda(dst, src)
+        if not act_ok(dst):
+            raise ValueError('ResizeAdd: dst must be a valid NHWC activation')
+        src = as_act(src)
+        ctx.in_size = (src.shape[1], src.shape[2])
+        ctx.mode = mode
+        resize_fwd(src, (dst.shape[1], dst.shape[2]), mode, out=dst, accumulate=True)
+        ctx.mark_dirty(dst)
+        return dst
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = as_act(dy)
+        return dy, resize_bwd(dy, ctx.in_size, ctx.mode), None
+
+
+class AdaptiveAvgPool(Function):
+    """nn.AdaptiveAvgPool2d(s) (model/upernext.py:62)."""
+
+    @staticmethod
+    def forward(ctx, x, s: int):
+        _require_cuda(x)
+        x = as_act(x)
+        B, H, W, Cp = x.shape
+        y = new_act(B, s, s, Cp, x)
+        check(lib.vkas_adaptive_avgpool_fwd(_p(x), act_ld(x), _p(y), Cp, B, H, W, s, Cp, _dt(x), _stream()),
+              'adaptive_avgpool_fwd')
+        ctx.cfg = (H, W, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        H, W, s = ctx.cfg
+        dy = as_act(dy)
+        B, _, _, Cp = dy.shape
+        dx = new_act(B, H, W, Cp, dy)
+        check(lib.vkas_adaptive_avgpool_bwd(_p(dy), act_ld(dy), _p(dx), Cp, B, H, W, s, Cp, 0, _dt(dy), _stream()),
+              'adaptive_avgpool_bwd')
+        return dx, None
+
+
+class Cat(Function):
+    """torch.cat along channels (model/upernext.py:82,197, model/fpn.py:144): each part is written into its channel
+    slice of one NHWC buffer; backward hands out slices (views) of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        _require_cuda(*parts)
+        parts = [as_act(p) for p in parts]
+        B, H, W, _ = parts[0].shape
+        widths = [p.shape[3] for p in parts]
+        out = new_act(B, H, W, sum(widths), parts[0])
+        off = 0
+        for p, w in zip(parts, widths):
+            copy_channels(p, out[..., off:off + w])
+            off += w
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = as_act(dy)
+        outs, off = [], 0
+        for w in ctx.widths:
+            outs.append(dy[..., off:off + w])
+            off += w
+        return tuple(outs)
+
+
+class ToNchw(Function):
+    """(B,H,W,Cp) activation -> (B,C,H,W) fp32 NCHW: the permute back of model/upernext.py:223 / fpn.py:183 for the
+    1..4-channel head outputs."""
+
+    @staticmethod
+    def forward(ctx, x, C: int):
+        _require_cuda(x)
+        x = as_act(x)
+        B, H, W, Cp = x.shape
+        out = torch.empty((B, C, H, W), dtype=_FLOAT, device=x.device)
+        check(lib.vkas_nhwc_to_nchw_f32(_p(x), act_ld(x), _p(out), B, H, W, C, _dt(x), _stream()), 'nhwc_to_nchw_f32')
+        ctx.cfg = (Cp, x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Cp, dtype = ctx.cfg
+        g = g.contiguous().float()
+        B, C, H, W = g.shape
+        out = torch.empty((B, H, W, Cp), dtype=dtype, device=g.device)
+        check(lib.vkas_nchw_f32_to_nhwc(_p(g), _p(out), Cp, B, H, W, C, Cp,
+                                        _lib.BF16 if dtype == torch.bfloat16 else _lib.F32, _stream()),
+              'nchw_f32_to_nhwc')
+        return out, None
+
+
+class Softplus(Function):
+    """nn.Softplus() (model/adaptive_scaling.py:101,140)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib.vkas_softplus_fwd(_p(x), _p(y), x.numel(), _stream()), 'softplus_fwd')
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        check(lib.vkas_softplus_bwd(_p(x), _p(dy), _p(dx), x.numel(), _stream()), 'softplus_bwd')
+        return dx
+
+
+class RoughLoss(Function):
+    """AdaptiveScalingRoughLossFunction.__call__ (loss_function/adaptive_scaling.py:53-131), default-active terms."""
+
+    @staticmethod
+    def forward(ctx, mask_feat, height_feat, gt_mask, gt_score, up, left, cfg):
+        _require_cuda(mask_feat, height_feat, gt_mask, gt_score)
+        mask_feat, height_feat = mask_feat.contiguous().float(), height_feat.contiguous().float()
+        gt_mask, gt_score = gt_mask.contiguous().float(), gt_score.contiguous().float()
+        B, _, H, W = mask_feat.shape
+        _, CH, CW = gt_mask.shape
+        sums = torch.empty((8,), dtype=torch.float64, device=mask_feat.device)
+        loss = torch.empty((), dtype=_FLOAT, device=mask_feat.device)
+        check(lib.vkas_rough_loss_fwd(_p(mask_feat), _p(height_feat), _p(gt_mask), _p(gt_score), B, H, W, up, left, CH,
+                                      CW, ctypes.byref(cfg), _p(sums), _p(loss), _stream()), 'rough_loss_fwd')
+        ctx.save_for_backward(mask_feat, height_feat, gt_mask, gt_score, sums)
+        ctx.cfg = (up, left, cfg)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        mask_feat, height_feat, gt_mask, gt_score, sums = ctx.saved_tensors
+        up, left, cfg = ctx.cfg
+        B, _, H, W = mask_feat.shape
+        _, CH, CW = gt_mask.shape
+        dm, dh = torch.empty_like(mask_feat), torch.empty_like(height_feat)
+        dloss = dloss.contiguous().float()
+        check(lib.vkas_rough_loss_bwd(_p(mask_feat), _p(height_feat), _p(gt_mask), _p(gt_score), B, H, W, up, left, CH,
+                                      CW, ctypes.byref(cfg), _p(sums), _p(dloss), _p(dm), _p(dh), _stream()),
+              'rough_loss_bwd')
+        return dm, dh, None, None, None, None, None
+
+
+class PreciseLoss(Function):
+    """AdaptiveScalingPreciseLossFunction.__call__ (loss_function/adaptive_scaling.py:181-346), default-active terms."""
+
+    @staticmethod
+    def forward(ctx, prob, offset, angle, dist, gt_score, gt_mask, py, px, gt_off, gt_ang, gt_dist, up, left, cfg):
+        _require_cuda(prob, offset, angle, dist)
+        f = lambda t: t.contiguous().float()
+        prob, offset, angle, dist = f(prob), f(offset), f(angle), f(dist)
+        gt_score, gt_mask, gt_off, gt_ang, gt_dist = f(gt_score), f(gt_mask), f(gt_off), f(gt_ang), f(gt_dist)
+        py, px = py.contiguous().long(), px.contiguous().long()
+        B, _, H, W = prob.shape
+        _, CH, CW = gt_mask.shape
+        P = py.shape[1]
+        sums = torch.empty((8,), dtype=torch.float64, device=prob.device)
+        loss = torch.empty((), dtype=_FLOAT, device=prob.device)
+        check(lib.vkas_precise_loss_fwd(_p(prob), _p(offset), _p(angle), _p(dist), _p(gt_score), _p(gt_mask), _p(py),
+                                        _p(px), _p(gt_off), _p(gt_ang), _p(gt_dist), B, H, W, up, left, CH, CW, P,
+                                        ctypes.byref(cfg), _p(sums), _p(loss), _stream()), 'precise_loss_fwd')
+        ctx.save_for_backward(prob, offset, angle, dist, gt_score, gt_mask, py, px, gt_off, gt_ang, gt_dist, sums)
+        ctx.cfg = (up, left, cfg)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        prob, offset, angle, dist, gt_score, gt_mask, py, px, gt_off, gt_ang, gt_dist, sums = ctx.saved_tensors
+        up, left, cfg = ctx.cfg
+        B, _, H, W = prob.shape
+        _, CH, CW = gt_mask.shape
+        P = py.shape[1]
+        dp, do, da, dd = (torch.empty_like(t) for t in (prob, offset, angle, dist))
+        dloss = dloss.contiguous().float()
+        check(lib.vkas_precise_loss_bwd(_p(prob), _p(offset), _p(angle), _p(dist), _p(gt_score), _p(gt_mask), _p(py),
+                                        _p(px), _p(gt_off), _p(gt_ang), _p(gt_dist), B, H, W, up, left, CH, CW, P,
+                                        ctypes.byref(cfg), _p(sums), _p(dloss), _p(dp), _p(do), _p(da), _p(dd),
+                                        _stream()), 'precise_loss_bwd')
+        return (dp, do, da, dd) + (None,) * 10

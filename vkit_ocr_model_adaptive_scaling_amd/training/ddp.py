@@ -1,0 +1,148 @@
+"""Data-parallel gradient reduction for the two-pass adaptive-scaling step.
+
+The reference has no distributed code; torch's DistributedDataParallel cannot wrap this model (no ``forward()``, two
+passes per step whose parameter sets differ, backbone gradients only final after the second backward).  This reducer
+all-reduces contiguous ranges ("buckets") of the flat gradient buffer as soon as they are final:
+
+  * after backward #1 (rough): the rough neck + rough heads range — it overlaps the entire precise pass;
+  * during backward #2 (precise): the precise heads/neck range, then backbone stage 3, 2, 1, 0 + stem, each launched
+    from a post-accumulate-grad hook when the last parameter of the bucket has received its gradient.
+
+Backbone buckets are armed only for the second backward (their gradients are partial after the first).  Collectives
+are ``torch.distributed.all_reduce(..., async_op=True)`` on slices of the flat buffer: with the ``nccl`` backend that
+is RCCL over xGMI on its own stream, ordered after the compute stream at launch and joined by ``wait()`` before the
+clip + AdamW kernels.  Gradients are averaged by pre-scaling the losses with 1/world_size.  Works with ``gloo`` on CPU
+tensors as well (tests)."""
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .flat import FlatBuffers
+
+
+class Bucket:
+
+    def __init__(self, name: str, start: int, end: int, param_names: Sequence[str]):
+        self.name, self.start, self.end = name, start, end
+        self.param_names = list(param_names)
+        self.pending = 0
+        self.armed = False
+
+
+class BucketedGradReducer:
+
+    def __init__(self, flat: FlatBuffers, bucket_prefixes: Sequence[Tuple[str, Tuple[str, ...]]],
+                 process_group=None):
+        self.flat = flat
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.buckets: Dict[str, Bucket] = {}
+        self._param_bucket: Dict[str, Bucket] = {}
+        covered = set()
+        for name, prefixes in bucket_prefixes:
+            start, end = flat.range_of(tuple(prefixes))
+            names = [n for n in flat.names if n.startswith(tuple(prefixes))]
+            b = Bucket(name, start, end, names)
+            self.buckets[name] = b
+            for n in names:
+                if n in covered:
+                    raise ValueError(f'{n} belongs to two buckets')
+                covered.add(n)
+                self._param_bucket[n] = b
+        missing = [n for n in flat.names if n not in covered]
+        if missing:
+            raise ValueError(f'parameters without a bucket: {missing[:4]}...')
+        self._works: List = []
+        self.launch_log: List[str] = []  # bucket names in launch order (inspected by tests)
+        for n, p in zip(flat.names, flat.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(n))
+
+    def _make_hook(self, name: str) -> Callable:
+        def hook(param):
+            b = self._param_bucket[name]
+            if not b.armed:
+                return
+            b.pending -= 1
+            if b.pending == 0:
+                b.armed = False
+                self._launch(b)
+        return hook
+
+    def arm(self, bucket_names: Sequence[str], expected: Optional[Dict[str, int]] = None):
+        """Arm buckets for the next backward: each launches when all its parameters have accumulated a gradient.
+        ``expected`` overrides the number of parameters that will receive a gradient in this pass."""
+        for bn in bucket_names:
+            b = self.buckets[bn]
+            b.pending = expected[bn] if expected and bn in expected else len(b.param_names)
+            b.armed = b.pending > 0
+
+    def _launch(self, b: Bucket):
+        self.launch_log.append(b.name)
+        if self.world_size == 1:
+            return
+        work = dist.all_reduce(self.flat.flat_grad[b.start:b.end], op=dist.ReduceOp.SUM, group=self.group,
+                               async_op=True)
+        self._works.append(work)
+
+    def flush(self, bucket_names: Sequence[str] = ()):
+        """Launch any still-armed bucket (a parameter that got no gradient keeps its bucket from firing) and
+        explicitly named ones, then wait for every outstanding collective."""
+        for b in self.buckets.values():
+            if b.armed or b.name in bucket_names:
+                b.armed = False
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        self._works.clear()
+
+
+def adaptive_scaling_buckets(model) -> List[Tuple[str, Tuple[str, ...]]]:
+    """Bucket layout for AdaptiveScaling: finalisation order rough -> precise -> backbone stages (reverse)."""
+    n_blocks = len(model.backbone.blocks)
+    buckets = [('rough', ('rough_neck.', 'rough_char_mask_head.', 'rough_char_height_head.')),
+               ('precise', ('precise_neck.', 'precise_char_mask_head.', 'precise_char_prob_head.',
+                            'precise_char_up_left_corner_offset_head.', 'precise_char_corner_angle_head.',
+                            'precise_char_corner_distance_head.'))]
+    for i in range(n_blocks - 1, 0, -1):
+        buckets.append((f'backbone{i}', (f'backbone.blocks.{i}.',)))
+    buckets.append(('backbone0', ('backbone.stem.', 'backbone.blocks.0.')))
+    return buckets
+
+
+class TwoPassStep:
+    """One training step with the reference's semantics (train.py:397-478): rough forward/loss/backward, precise
+    forward/loss/backward (gradients accumulate), gradient all-reduce, global-norm clip, AdamW."""
+
+    def __init__(self, model, rough_loss_fn, precise_loss_fn, optimizer, reducer: Optional[BucketedGradReducer] = None):
+        self.model, self.rough_loss_fn, self.precise_loss_fn = model, rough_loss_fn, precise_loss_fn
+        self.optimizer, self.reducer = optimizer, reducer
+        self.world = reducer.world_size if reducer is not None else 1
+        self._backbone_buckets = [b for b in (reducer.buckets if reducer else {}) if b.startswith('backbone')]
+
+    def __call__(self, rough_batch: dict, precise_batch: dict, lr: Optional[float] = None):
+        scale = 0.5 / self.world  # train.py:413,451 (loss / 2), averaged over ranks
+        r = self.reducer
+        mask, height = self.model.forward_rough(rough_batch['image'])
+        rough_loss = self.rough_loss_fn(mask, height, rough_batch['downsampled_mask'],
+                                        rough_batch['downsampled_score_map'], rough_batch['downsampled_shape'],
+                                        rough_batch['downsampled_core_box'], scale=scale)
+        if r is not None:
+            r.arm(['rough'])
+        rough_loss.backward()
+        prob, offset, angle, dist_ = self.model.forward_precise(precise_batch['image'])
+        precise_loss = self.precise_loss_fn(None, prob, offset, angle, dist_, precise_batch['downsampled_score_map'],
+                                            precise_batch['downsampled_mask'], precise_batch['downsampled_shape'],
+                                            precise_batch['downsampled_core_box'],
+                                            precise_batch['downsampled_label_point_y'],
+                                            precise_batch['downsampled_label_point_x'],
+                                            precise_batch['up_left_offsets'], precise_batch['corner_angles'],
+                                            precise_batch['corner_distances'], scale=scale)
+        if r is not None:
+            r.arm(['precise'] + self._backbone_buckets)
+        precise_loss.backward()
+        if r is not None:
+            r.flush()
+        self.optimizer.step(lr=lr)
+        self.optimizer.zero_grad()
+        return rough_loss.detach(), precise_loss.detach()

@@ -1,0 +1,63 @@
+"""Flat parameter / gradient storage.
+
+All parameters of a model become views into one fp32 buffer and all ``.grad`` tensors views into a second one
+(registration order, each tensor aligned to 16 bytes).  The gradient buffer is what RCCL all-reduces (contiguous
+ranges = buckets) and what the fused clip + AdamW kernels walk; autograd accumulates into the views in place, so the
+two backward passes of a step (train.py:416,454) sum without extra copies.  Device-agnostic (the CPU/gloo tests of the
+reducer use it too)."""
+from typing import Dict, Iterable, List, Tuple
+
+import torch
+from torch import nn
+
+ALIGN = 4  # elements (16 bytes of fp32)
+
+
+class FlatBuffers:
+
+    def __init__(self, named_params: Iterable[Tuple[str, nn.Parameter]]):
+        named_params = [(n, p) for n, p in named_params if p.requires_grad]
+        if not named_params:
+            raise ValueError('no trainable parameters')
+        device = named_params[0][1].device
+        self.names: List[str] = []
+        self.params: List[nn.Parameter] = []
+        self.offsets: Dict[str, Tuple[int, int]] = {}
+        total = 0
+        for n, p in named_params:
+            if p.dtype != torch.float32:
+                raise TypeError(f'{n}: master parameters must be fp32')
+            self.offsets[n] = (total, p.numel())
+            total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            self.names.append(n)
+            self.params.append(p)
+        self.numel = total
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for n, p in named_params:
+                start, size = self.offsets[n]
+                view = self.flat_param[start:start + size].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_grad[start:start + size].view(p.shape)
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for n, p in zip(self.names, self.params):  # re-attach views if someone set .grad to None
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * self.offsets[n][0]:
+                start, size = self.offsets[n]
+                p.grad = self.flat_grad[start:start + size].view(p.shape)
+
+    def range_of(self, prefixes: Tuple[str, ...]) -> Tuple[int, int]:
+        """Smallest [start, end) element range covering every parameter whose name starts with one of ``prefixes``;
+        raises if a foreign parameter lies inside (ranges must be contiguous to be all-reduced in one call)."""
+        sel = [n for n in self.names if n.startswith(prefixes)]
+        if not sel:
+            raise KeyError(prefixes)
+        start = min(self.offsets[n][0] for n in sel)
+        end = max(self.offsets[n][0] + (self.offsets[n][1] + ALIGN - 1) // ALIGN * ALIGN for n in sel)
+        inside = [n for n in self.names if start <= self.offsets[n][0] < end]
+        if set(inside) != set(sel):
+            raise ValueError(f'parameters {prefixes} are not contiguous in the flat buffer')
+        return start, end
