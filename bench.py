@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s of the full adaptive-scaling train step (ConvNeXt-T + UPerNext + 6 heads, both
+passes, both losses, backward, gradient all-reduce, clip, AdamW) on synthetic 1024x1024 inputs, bf16, B=8 per pass
+and GPU (BASELINE.json configs[2]; weak scaling over GPUs = configs[3]).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  ``roofline`` describes the dominant kernel (the bf16 MFMA implicit-GEMM that runs
+the head 3x3 convolutions, their dgrads and every 1x1): algorithmic FLOPs per launch / average launch duration,
+both measured with HIP events on the launch stream during the timed steps.  ``cpu_baseline`` is the oracle
+(oracle/torch_oracle.py, a CPU restatement of the reference pinned to the reference's outputs) timed on the host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+
+
+def synthetic_batches(batch, hw, device, seed):
+    """raw 0..255 pixels; rough gt mask/score map; precise score map/mask/label points; margin 10."""
+    import torch
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    H, W = hw
+    dh, dw = H // 2, W // 2
+    from vkit_ocr_model_adaptive_scaling_amd.loss_function import Box
+    box = Box(up=10, down=dh - 11, left=10, right=dw - 11)
+    ch, cw = dh - 20, dw - 20
+    P = 200  # train.py:58
+    r = lambda *s: torch.rand(*s, generator=g)
+    rough = dict(image=torch.randint(0, 256, (batch, 3, H, W), generator=g).float(),
+                 downsampled_mask=(r(batch, ch, cw) > 0.5).float(), downsampled_score_map=r(batch, ch, cw) + 8.75,
+                 downsampled_shape=(dh, dw), downsampled_core_box=box)
+    precise = dict(image=torch.randint(0, 256, (batch, 3, H, W), generator=g).float(),
+                   downsampled_mask=(r(batch, ch, cw) > 0.5).float(), downsampled_score_map=r(batch, ch, cw),
+                   downsampled_shape=(dh, dw), downsampled_core_box=box,
+                   downsampled_label_point_y=torch.randint(10, dh - 10, (batch, P), generator=g),
+                   downsampled_label_point_x=torch.randint(10, dw - 10, (batch, P), generator=g),
+                   up_left_offsets=torch.randint(-20, 21, (batch, P, 2), generator=g).float(),
+                   corner_angles=torch.softmax(r(batch, P, 4), dim=-1), corner_distances=r(batch, P, 3))
+    mv = lambda d: {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
+    return mv(rough), mv(precise)
+
+
+def cpu_baseline(hw, seed):
+    """One reference-semantics step (B=1 rough + B=1 precise) of the oracle on the host cores, fp32."""
+    import torch
+    from oracle import torch_oracle as O
+    from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
+                                                           AdaptiveScalingNeckHeadType)
+    torch.manual_seed(seed)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.TINY, AdaptiveScalingNeckHeadType.UPERNEXT))
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    rough, precise = synthetic_batches(1, hw, 'cpu', seed)
+    box = rough['downsampled_core_box']
+    cb = (box.up, box.down, box.left, box.right)
+    t0 = time.perf_counter()
+    m, h = O.forward_rough(sd, rough['image'], 'upernext')
+    (O.rough_loss(m, h, rough['downsampled_mask'], rough['downsampled_score_map'], cb) / 2).backward()
+    outs = O.forward_precise(sd, precise['image'], 'upernext')
+    (O.precise_loss(*outs, precise['downsampled_score_map'], precise['downsampled_mask'], cb,
+                    precise['downsampled_label_point_y'], precise['downsampled_label_point_x'],
+                    precise['up_left_offsets'], precise['corner_angles'], precise['corner_distances']) / 2).backward()
+    dt = time.perf_counter() - t0
+    return {'value': 2.0 / dt, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'1 step of the oracle (B=1 rough + B=1 precise, {hw[0]}x{hw[1]}, fp32, ConvNeXt-T+UPerNext, '
+                      f'fwd+loss+bwd both passes, no optimizer): {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--size', type=int, default=1024)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from vkit_ocr_model_adaptive_scaling_amd import ops
+    from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
+                                                           AdaptiveScalingNeckHeadType)
+    from vkit_ocr_model_adaptive_scaling_amd.loss_function import (
+        AdaptiveScalingRoughLossFunction, AdaptiveScalingRoughLossFunctionConifg, AdaptiveScalingPreciseLossFunction,
+        AdaptiveScalingPreciseLossFunctionConifg)
+    from vkit_ocr_model_adaptive_scaling_amd.training import (FlatBuffers, FlatAdamW, BucketedGradReducer, TwoPassStep,
+                                                              adaptive_scaling_buckets, cosine_warm_restarts_lr)
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    torch.manual_seed(1234)  # identical initial weights on every rank
+    model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.TINY, AdaptiveScalingNeckHeadType.UPERNEXT),
+                            compute_dtype=dtype).to(device).train()
+    flat = FlatBuffers(model.named_parameters())
+    opt = FlatAdamW(None, lr=8e-4, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=2.5, flat=flat)
+    reducer = BucketedGradReducer(flat, adaptive_scaling_buckets(model)) if world > 1 else None
+    step = TwoPassStep(model, AdaptiveScalingRoughLossFunction(AdaptiveScalingRoughLossFunctionConifg()),
+                       AdaptiveScalingPreciseLossFunction(AdaptiveScalingPreciseLossFunctionConifg()), opt, reducer)
+    hw = (args.size, args.size)
+    rough, precise = synthetic_batches(args.batch, hw, device, 1337 + rank)
+    torch.manual_seed(99 + rank)  # stochastic-depth masks differ per rank
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(args.warmup):
+        step(rough, precise, lr=cosine_warm_restarts_lr(it / 1000.0, 8e-4, 8e-6, 10, 10))
+        it += 1
+    sync()
+    ops.TIMER = ops.LaunchTimer()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step(rough, precise, lr=cosine_warm_restarts_lr(it / 1000.0, 8e-4, 8e-6, 10, 10))
+        it += 1
+    sync()
+    elapsed = time.perf_counter() - t0
+    timer, ops.TIMER = ops.TIMER, None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    rl, pl = float(losses[0]), float(losses[1])
+    if not (rl == rl and pl == pl):
+        raise SystemExit('non-finite loss in the timed region')
+
+    if rank == 0:
+        ms = 1000.0 * elapsed / args.steps
+        images = 2 * args.batch * world  # one rough + one precise batch per rank per step
+        summ = timer.summary()
+        dom = 'gemm_nt_mfma' if dtype == torch.bfloat16 else 'gemm_nt_simple'
+        d = summ.get(dom, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
+        achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
+        roof = {'bound': 'mfma', 'kernel': 'gemm_nt_mfma_kernel (implicit-GEMM conv fwd/dgrad, bf16 16x16x32 MFMA)',
+                'achieved': round(achieved, 2), 'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), 'traffic': None,
+                'launches_per_step': d['launches'] / max(args.steps, 1),
+                'avg_launch_ms': round(d['ms'] / max(d['launches'], 1), 4),
+                'flops_per_launch': d['flops'] / max(d['launches'], 1),
+                'share_of_step_time': round(d['ms'] / (1000.0 * elapsed), 3),
+                'other_kernels': {k: {'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else 0.0,
+                                      'share_of_step_time': round(v['ms'] / (1000.0 * elapsed), 3)}
+                                  for k, v in summ.items() if k != dom}}
+        out = {'metric': 'images/sec fwd+bwd @1024x1024 bf16 (train step: rough+precise passes, losses, backward, '
+                         'clip, AdamW)', 'value': round(images / (elapsed / args.steps), 3), 'unit': 'images/s',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+               'data': 'synthetic', 'config': {'workload': f'ConvNeXt-T + UPerNext + adaptive-scaling heads fwd+bwd '
+                                                           f'{args.size}x{args.size}, batch {args.batch} per pass per GPU '
+                                                           f'(BASELINE.json configs[2]{"/[3]" if world > 1 else ""})',
+                                               'global_batch': args.batch * world, 'images_per_step': images,
+                                               'parallelism': f'dp{world}', 'losses': [round(rl, 5), round(pl, 5)]},
+               'roofline': roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(hw, 1337)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

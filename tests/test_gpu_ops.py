@@ -76,6 +76,7 @@ CONV_CASES = [
     (1, 3, 32, 64, 16, 4, 4, 0),
     (1, 3, 32, 64, 16, 2, 2, 0),
     (3, 200, 17, 9, 136, 1, 1, 0),
+    (1, 64, 6, 5, 3072, 1, 1, 0),  # > 2048 output channels (stage-3 MLP width): bias-grad column sums in two passes
 ]
 
 

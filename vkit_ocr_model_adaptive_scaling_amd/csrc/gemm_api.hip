@@ -97,7 +97,8 @@ static inline long cs_rows_per_block(long M) { long r = vkas_cdiv(M > 0 ? M : 1,
 // partial[blk][c] = sum over this block's rows of y[m][c]; thread = one 8-channel vector, rows strided.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ y, long ld, long M, int Np,
-                                                             long rows_per_block, float* __restrict__ partial) {
+                                                             long rows_per_block, float* __restrict__ partial,
+                                                             int ldp) {
   const int nvec = Np >> 3;
   const int lanes_r = 256 / nvec > 0 ? 256 / nvec : 1;  // row lanes per block (nvec <= 256 checked by host)
   const int v = threadIdx.x % nvec;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     for (int r = 1; r < lanes_r; ++r)
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] += red[(r * nvec + v) * 8 + i];
-    float* dst = partial + (long)blockIdx.x * Np + v * 8;
+    float* dst = partial + (long)blockIdx.x * ldp + v * 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) dst[i] = acc[i];
   }
@@ -161,7 +162,7 @@ extern "C" size_t vkas_colsum_ws_bytes(long M, int Np) {
 extern "C" int vkas_colsum(const void* y, long ld, long M, int Np, float* out, int accumulate, float* ws,
                            size_t ws_bytes, int dtype, void* stream) {
   VKAS_CHECK(y && out && ws, "vkas_colsum: null pointer");
-  VKAS_CHECK(Np > 0 && Np % 8 == 0 && Np <= 2048, "vkas_colsum: Np=%d must be a multiple of 8, <= 2048", Np);
+  VKAS_CHECK(Np > 0 && Np % 8 == 0, "vkas_colsum: Np=%d must be a positive multiple of 8", Np);
   VKAS_CHECK(ld >= Np && ld % 8 == 0 && vkas_aligned16(y), "vkas_colsum: bad ld/alignment");
   VKAS_CHECK(ws_bytes >= vkas_colsum_ws_bytes(M, Np), "vkas_colsum: workspace too small");
   if (M <= 0) {
@@ -171,7 +172,10 @@ extern "C" int vkas_colsum(const void* y, long ld, long M, int Np, float* out, i
   const long rpb = cs_rows_per_block(M);
   const long P = vkas_cdiv(M, rpb);
   VKAS_DISPATCH_DTYPE(dtype, "vkas_colsum", {
-    colsum_partial_kernel<T><<<(unsigned)P, 256, 0, vkas_stream(stream)>>>((const T*)y, ld, M, Np, rpb, ws);
+    for (int c0 = 0; c0 < Np; c0 += 2048) {  // 256 threads cover at most 256 8-channel vectors per pass
+      const int n = Np - c0 < 2048 ? Np - c0 : 2048;
+      colsum_partial_kernel<T><<<(unsigned)P, 256, 0, vkas_stream(stream)>>>((const T*)y + c0, ld, M, n, rpb, ws + c0, Np);
+    }
   })
   VKAS_LAUNCH_CHECK("colsum_partial");
   return vkas_colreduce_finalize(ws, P, Np, Np, out, accumulate, vkas_stream(stream));

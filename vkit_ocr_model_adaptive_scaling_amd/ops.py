@@ -112,9 +112,54 @@ def _geom(B, Hin, Win, Hout, Wout, Cp, ldx, KH, KW, stride, pad) -> ConvGeom:
     return ConvGeom(B, Hin, Win, Hout, Wout, Cp, ldx, KH, KW, stride, pad)
 
 
+class LaunchTimer:
+    """Optional per-launch HIP-event timing of the implicit-GEMM kernels (bench.py's roofline leg).  Events are
+    recorded on torch's current stream, which is the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.records = []  # (kind, start_event, end_event, flops, M, N, K)
+
+    def summary(self):
+        out = {}
+        for kind, s, e, flops, M, N, K in self.records:
+            d = out.setdefault(kind, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
+            d['launches'] += 1
+            d['ms'] += s.elapsed_time(e)
+            d['flops'] += flops
+        return out
+
+
+TIMER: Optional[LaunchTimer] = None
+
+
+def _timed(kind, x, flops, M, N, K, fn):
+    if TIMER is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = fn()
+    e.record()
+    TIMER.records.append((kind, s, e, flops, M, N, K))
+    return r
+
+
 def conv_gemm(x: torch.Tensor, geom: ConvGeom, Bw: torch.Tensor, Np: int, out: torch.Tensor, mode=_lib.EPI_NONE,
               bias=None, out2=None, aux=None, colscale=None, rowscale=None, rows_per_image=0, patch=0, patch_hw=(0, 0),
-              patch_Cp=0):
+              patch_Cp=0, nk=None):
+    if TIMER is not None:
+        # algorithmic FLOPs use the logical (unpadded) N and K when the caller knows them
+        M = geom.B * geom.Hout * geom.Wout
+        N, K = nk if nk is not None else (Np, geom.KH * geom.KW * geom.Cp)
+        kind = ('gemm_nt_mfma' if x.dtype == torch.bfloat16 else 'gemm_nt_simple')
+        return _timed(kind, x, 2.0 * M * N * K, M, N, K,
+                      lambda: _conv_gemm(x, geom, Bw, Np, out, mode, bias, out2, aux, colscale, rowscale, rows_per_image,
+                                         patch, patch_hw, patch_Cp))
+    return _conv_gemm(x, geom, Bw, Np, out, mode, bias, out2, aux, colscale, rowscale, rows_per_image, patch, patch_hw,
+                      patch_Cp)
+
+
+def _conv_gemm(x, geom, Bw, Np, out, mode, bias, out2, aux, colscale, rowscale, rows_per_image, patch, patch_hw,
+               patch_Cp):
     epi = Epilogue(mode, _p(bias).value if bias is not None else None, out.data_ptr(), act_ld(out),
                    out2.data_ptr() if out2 is not None else None, act_ld(out2) if out2 is not None else 0,
                    aux.data_ptr() if aux is not None else None, act_ld(aux) if aux is not None else 0,
@@ -126,12 +171,18 @@ def conv_gemm(x: torch.Tensor, geom: ConvGeom, Bw: torch.Tensor, Np: int, out: t
     return out
 
 
-def conv_wgrad(x: torch.Tensor, geom: ConvGeom, dy: torch.Tensor, Np: int) -> torch.Tensor:
+def conv_wgrad(x: torch.Tensor, geom: ConvGeom, dy: torch.Tensor, Np: int, nk=None) -> torch.Tensor:
     K = geom.KH * geom.KW * geom.Cp
     gw = torch.zeros((Np * K,), dtype=_FLOAT, device=x.device)
-    check(lib.vkas_conv_gemm_wgrad(_p(x), ctypes.byref(geom), _p(dy), act_ld(dy), Np, _p(gw), _dt(x), _stream()),
-          'conv_gemm_wgrad')
-    return gw
+    M = geom.B * geom.Hout * geom.Wout
+
+    def run():
+        check(lib.vkas_conv_gemm_wgrad(_p(x), ctypes.byref(geom), _p(dy), act_ld(dy), Np, _p(gw), _dt(x), _stream()),
+              'conv_gemm_wgrad')
+        return gw
+    kind = 'gemm_tn_mfma' if x.dtype == torch.bfloat16 else 'gemm_tn_simple'
+    N, Kl = nk if nk is not None else (Np, K)
+    return _timed(kind, x, 2.0 * M * N * Kl, M, N, Kl, run)
 
 
 def unpack_wgrad(gw: torch.Tensor, shape4, Np: int, Cp: int) -> torch.Tensor:
@@ -247,7 +298,7 @@ class Conv(Function):
         Bw = pack_conv_weight(w4, Np, Cp, 0, x.dtype)
         out = new_act(B, Hout, Wout, Np, x)
         geom = _geom(B, Hin, Win, Hout, Wout, Cp, act_ld(x), KH, KW, stride, pad)
-        conv_gemm(x, geom, Bw, Np, out, _lib.EPI_NONE, bias=pad_vector(bias, Np))
+        conv_gemm(x, geom, Bw, Np, out, _lib.EPI_NONE, bias=pad_vector(bias, Np), nk=(N, C * KH * KW))
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, bias is not None, need_input_grad)
         return out
@@ -262,7 +313,7 @@ class Conv(Function):
         B, Hin, Win, Cp = x.shape
         _, Hout, Wout, Np = dy.shape
         geom = _geom(B, Hin, Win, Hout, Wout, Cp, act_ld(x), KH, KW, stride, pad)
-        gw = unpack_wgrad(conv_wgrad(x, geom, dy, Np), (N, C, KH, KW), Np, Cp).view(weight.shape)
+        gw = unpack_wgrad(conv_wgrad(x, geom, dy, Np, nk=(N, C * KH * KW)), (N, C, KH, KW), Np, Cp).view(weight.shape)
         gb = colsum(dy, N) if has_bias else None
         dx = None
         if need_input_grad and ctx.needs_input_grad[0]:
@@ -271,14 +322,15 @@ class Conv(Function):
                 Bt = pack_conv_weight(w4, Np, Cp, 1, x.dtype)
                 dx = new_act(B, Hin, Win, Cp, x)
                 g2 = _geom(B, Hout, Wout, Hin, Win, Np, act_ld(dy), KH, KW, 1, KH - 1 - pad)
-                conv_gemm(dy, g2, Bt, Cp, dx, _lib.EPI_NONE)
+                conv_gemm(dy, g2, Bt, Cp, dx, _lib.EPI_NONE, nk=(C, N * KH * KW))
             else:
                 assert stride == KH == KW and pad == 0
                 Bt = pack_conv_weight(w4, Np, Cp, 2, x.dtype)
                 full = (Hout * stride == Hin and Wout * stride == Win)
                 dx = new_act(B, Hin, Win, Cp, x) if full else torch.zeros_like(x, memory_format=torch.contiguous_format)
                 g2 = _geom(B, Hout, Wout, Hout, Wout, Np, act_ld(dy), 1, 1, 1, 0)
-                conv_gemm(dy, g2, Bt, KH * KW * Cp, dx, _lib.EPI_PATCH, patch=KH, patch_hw=(Hout, Wout), patch_Cp=Cp)
+                conv_gemm(dy, g2, Bt, KH * KW * Cp, dx, _lib.EPI_PATCH, patch=KH, patch_hw=(Hout, Wout), patch_Cp=Cp,
+                          nk=(C * KH * KW, N))
         return dx, gw, gb, None, None, None
 
 
