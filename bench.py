@@ -50,6 +50,19 @@ def synthetic_batches(batch, hw, device, seed):
     return mv(rough), mv(precise)
 
 
+def usable_cores() -> int:
+    """CPU share of this process: affinity mask, capped by the cgroup quota (the GPU box exposes all host cores but
+    grants a 16-core share per GPU; oversubscribing them makes the CPU leg meaningless)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get('VKAS_CPU_THREADS', '16'))))
+
+
 def cpu_baseline(hw, seed):
     """One reference-semantics step (B=1 rough + B=1 precise) of the oracle on the host cores, fp32."""
     import torch
@@ -57,7 +70,7 @@ def cpu_baseline(hw, seed):
     from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
                                                            AdaptiveScalingNeckHeadType)
     torch.manual_seed(seed)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.TINY, AdaptiveScalingNeckHeadType.UPERNEXT))
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
@@ -86,6 +99,7 @@ def main():
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--detail', action='store_true', help='per-shape GEMM timing table on stderr')
     args = ap.parse_args()
 
     import torch
@@ -149,9 +163,22 @@ def main():
         raise SystemExit('non-finite loss in the timed region')
 
     if rank == 0:
+        print(f'[bench] {args.steps} steps in {elapsed:.3f} s on {world} GPU(s); losses {rl:.4f} {pl:.4f}', file=sys.stderr,
+              flush=True)
         ms = 1000.0 * elapsed / args.steps
         images = 2 * args.batch * world  # one rough + one precise batch per rank per step
         summ = timer.summary()
+        if args.detail:
+            shapes = {}
+            for kind, s_, e_, flops, M, N, K in timer.records:
+                d_ = shapes.setdefault((kind, M, N, K), [0, 0.0, 0.0])
+                d_[0] += 1
+                d_[1] += s_.elapsed_time(e_)
+                d_[2] += flops
+            print('[bench] kind M N K launches/step ms/step TFLOP/s', file=sys.stderr)
+            for key, (n_, ms_, fl_) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                print(f'[bench] {key[0]:14s} {key[1]:8d} {key[2]:5d} {key[3]:5d} {n_ / args.steps:6.1f} '
+                      f'{ms_ / args.steps:8.3f} {fl_ / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0:8.1f}', file=sys.stderr)
         dom = 'gemm_nt_mfma' if dtype == torch.bfloat16 else 'gemm_nt_simple'
         d = summ.get(dom, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
         achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0

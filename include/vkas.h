@@ -118,7 +118,8 @@ int vkas_dwconv7x7_wgrad(const void* x, long ldx, const void* dy, long lddy, flo
 size_t vkas_dwconv7x7_wgrad_ws_bytes(int B, int H, int W, int Cp);
 
 /* ---- LayerNorm over C (+ optional GELU): helper.py:96-101 --------------------------------------- */
-/* y = act(LN(x) * gamma + beta); stats (M, 2) fp32 = (mean, rstd).  C = logical channels, pad channels -> 0. */
+/* y = act(LN(x) * gamma + beta); stats (M, 2) fp32 = (mean, rstd).  C = logical channels, pad channels -> 0.
+ * gamma / beta: Cp floats, zero padded beyond C (vkas_pad_vector). */
 int vkas_layernorm_fwd(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
                        float* stats, long M, int C, int Cp, int act_gelu, int dtype, void* stream);
 /* dx from dy; dgamma/dbeta (Cp) fp32 overwritten.  `x` is the forward input, `stats` from forward. */

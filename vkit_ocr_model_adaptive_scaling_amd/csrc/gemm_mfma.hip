@@ -189,6 +189,17 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const bf16_t* __restr
     kx = tap - ky * g.KW;
   }
 
+  // running (b, oy, ox) of the 4 rows this thread stages; advanced by TN_ROWS per iteration without divisions
+  int r_b[4], r_y[4], r_x[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const RowCoord rc = decode_row(mbeg + sr + 16 * i, M, g);
+    r_b[i] = rc.b;
+    r_y[i] = rc.oy;
+    r_x[i] = rc.ox;
+  }
+  const int kyo = ky - g.pad, kxo = kx - g.pad;
+
   bf16x8 rd[4], rx[4];
   auto load_tile = [&](long mc) {
 #pragma unroll
@@ -198,14 +209,21 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const bf16_t* __restr
       bf16x8 vx = {0, 0, 0, 0, 0, 0, 0, 0};
       if (m < mend) {
         if (n_ok) vd = *reinterpret_cast<const bf16x8*>(dy + m * lddy + nn);
-        if (k_ok) {
-          const RowCoord rc = decode_row(m, M, g);
-          const long off = tap_offset(rc, ky, kx, g);
-          if (off >= 0) vx = *reinterpret_cast<const bf16x8*>(x + off + c_in);
-        }
+        const int iy = r_y[i] * g.stride + kyo, ix = r_x[i] * g.stride + kxo;
+        if (k_ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win)
+          vx = *reinterpret_cast<const bf16x8*>(x + (((long)r_b[i] * g.Hin + iy) * g.Win + ix) * (long)g.ldx + c_in);
       }
       rd[i] = vd;
       rx[i] = vx;
+      // advance this row by TN_ROWS output pixels
+      r_x[i] += TN_ROWS;
+      while (r_x[i] >= g.Wout) {
+        r_x[i] -= g.Wout;
+        if (++r_y[i] == g.Hout) {
+          r_y[i] = 0;
+          ++r_b[i];
+        }
+      }
     }
   };
   auto store_tile = [&](int buf) {

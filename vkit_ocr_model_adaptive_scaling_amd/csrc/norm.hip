@@ -13,7 +13,7 @@ int vkas_colreduce_finalize(const float* partial, long P, int n, int ldp, float*
 
 namespace {
 
-constexpr int MAXV = 4;  // vectors per lane: Cp <= 8 * 64 * 4 = 2048
+constexpr int MAXV_LIMIT = 4;  // vectors per lane: Cp <= 8 * 64 * 4 = 2048
 
 __device__ __forceinline__ float group_sum(float v, int G) {
   for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -26,7 +26,7 @@ static inline int pick_group(int nvec) {
   return g;
 }
 
-template <typename T>
+template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, long ldx,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y, long ldy,
@@ -70,22 +70,21 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   for (int i = 0; i < MAXV; ++i) {
     const int vi = gl + i * G;
     if (vi >= nvec) continue;
-    float o[8];
+    // gamma / beta are zero padded to Cp, so pad channels come out as act(0) = 0 without a branch
+    float gv[8], bv[8], o[8];
+    load8(gamma + vi * 8, gv);
+    load8(beta + vi * 8, bv);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const int cc = vi * 8 + c;
-      float u = 0.f;
-      if (cc < C) {
-        u = (v[i][c] - mean) * rstd * gamma[cc] + beta[cc];
-        if (act_gelu) u = gelu_f(u);
-      }
+      float u = (v[i][c] - mean) * rstd * gv[c] + bv[c];
+      if (act_gelu) u = gelu_f(u);
       o[c] = u;
     }
     store8(y + m * ldy + vi * 8, o);
   }
 }
 
-template <typename T>
+template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, long ldx,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
@@ -108,8 +107,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       dg[i][c] = 0.f;
       db[i][c] = 0.f;
       const int cc = vi * 8 + c;
-      gm[i][c] = (vi < nvec && cc < C) ? gamma[cc] : 0.f;
-      bt[i][c] = (vi < nvec && cc < C) ? beta[cc] : 0.f;
+      gm[i][c] = (vi < nvec) ? gamma[cc] : 0.f;  // zero padded to Cp by the caller
+      bt[i][c] = (vi < nvec) ? beta[cc] : 0.f;
     }
   }
   for (long m0 = mbeg; m0 < mend; m0 += rpi) {
@@ -255,9 +254,16 @@ extern "C" int vkas_layernorm_fwd(const void* x, long ldx, const float* gamma, c
   if (M <= 0) return VKAS_OK;
   const int G = pick_group(Cp >> 3);
   const long rows = 256 / G;
+  const int vpl = (int)vkas_cdiv(Cp >> 3, G);
   VKAS_DISPATCH_DTYPE(dtype, "vkas_layernorm_fwd", {
-    layernorm_fwd_kernel<T><<<(unsigned)vkas_cdiv(M, rows), 256, 0, vkas_stream(stream)>>>(
-        (const T*)x, ldx, gamma, beta, (T*)y, ldy, stats, M, C, Cp, G, act_gelu);
+    const unsigned grid = (unsigned)vkas_cdiv(M, rows);
+    hipStream_t st = vkas_stream(stream);
+    if (vpl == 1)
+      layernorm_fwd_kernel<T, 1><<<grid, 256, 0, st>>>((const T*)x, ldx, gamma, beta, (T*)y, ldy, stats, M, C, Cp, G, act_gelu);
+    else if (vpl == 2)
+      layernorm_fwd_kernel<T, 2><<<grid, 256, 0, st>>>((const T*)x, ldx, gamma, beta, (T*)y, ldy, stats, M, C, Cp, G, act_gelu);
+    else
+      layernorm_fwd_kernel<T, 4><<<grid, 256, 0, st>>>((const T*)x, ldx, gamma, beta, (T*)y, ldy, stats, M, C, Cp, G, act_gelu);
   })
   VKAS_LAUNCH_CHECK("layernorm_fwd");
   return VKAS_OK;
@@ -288,9 +294,17 @@ extern "C" int vkas_layernorm_bwd(const void* x, long ldx, const float* gamma, c
   const int G = pick_group(Cp >> 3);
   const long rpb = rows_per_block_for(M, 256 / G);
   const long P = vkas_cdiv(M, rpb);
+  const int vpl = (int)vkas_cdiv(Cp >> 3, G);
   VKAS_DISPATCH_DTYPE(dtype, "vkas_layernorm_bwd", {
-    layernorm_bwd_kernel<T><<<(unsigned)P, 256, 0, st>>>((const T*)x, ldx, gamma, beta, stats, (const T*)dy, lddy,
-                                                         (T*)dx, lddx, ws, M, C, Cp, G, act_gelu, rpb);
+    if (vpl == 1)
+      layernorm_bwd_kernel<T, 1><<<(unsigned)P, 256, 0, st>>>((const T*)x, ldx, gamma, beta, stats, (const T*)dy, lddy,
+                                                              (T*)dx, lddx, ws, M, C, Cp, G, act_gelu, rpb);
+    else if (vpl == 2)
+      layernorm_bwd_kernel<T, 2><<<(unsigned)P, 256, 0, st>>>((const T*)x, ldx, gamma, beta, stats, (const T*)dy, lddy,
+                                                              (T*)dx, lddx, ws, M, C, Cp, G, act_gelu, rpb);
+    else
+      layernorm_bwd_kernel<T, 4><<<(unsigned)P, 256, 0, st>>>((const T*)x, ldx, gamma, beta, stats, (const T*)dy, lddy,
+                                                              (T*)dx, lddx, ws, M, C, Cp, G, act_gelu, rpb);
   })
   VKAS_LAUNCH_CHECK("layernorm_bwd");
   int rc = vkas_colreduce_finalize(ws, P, Cp, 2 * Cp, dgamma, 0, st);

@@ -208,6 +208,7 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, C: i
     M = B * H * W
     y = new_act(B, H, W, Cp, x) if out is None else out
     stats = torch.empty((M, 2), dtype=_FLOAT, device=x.device)
+    gamma, beta = pad_vector(gamma, Cp), pad_vector(beta, Cp)
     check(lib.vkas_layernorm_fwd(_p(x), act_ld(x), _p(gamma), _p(beta), _p(y), act_ld(y), _p(stats), M, C, Cp,
                                  int(act_gelu), _dt(x), _stream()), 'layernorm_fwd')
     return y, stats
@@ -221,6 +222,7 @@ def layernorm_bwd(x, gamma, beta, stats, dy, C: int, act_gelu: bool):
     db = torch.empty((Cp,), dtype=_FLOAT, device=x.device)
     nbytes = lib.vkas_layernorm_bwd_ws_bytes(M, Cp)
     ws = _ws(nbytes, x.device)
+    gamma, beta = pad_vector(gamma, Cp), pad_vector(beta, Cp)
     check(lib.vkas_layernorm_bwd(_p(x), act_ld(x), _p(gamma), _p(beta), _p(stats), _p(dy), act_ld(dy), _p(dx),
                                  act_ld(dx), _p(dg), _p(db), _p(ws), nbytes, M, C, Cp, int(act_gelu), _dt(x),
                                  _stream()), 'layernorm_bwd')
