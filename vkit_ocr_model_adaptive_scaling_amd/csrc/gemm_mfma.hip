@@ -9,42 +9,57 @@
 //  * gemm_tn_mfma (wgrad): gw[n][k] += sum_m dy[m][n] A(m,k).  Both operands are reduced along the slow
 //    (pixel) axis, so the LDS tiles are kept [m][col] and the fragments are fetched with the gfx950
 //    transposing LDS read (ds_read_b64_tr_b16).  Split over M, fp32 atomics into the (small) gw.
+#include <stdlib.h>
+
 #include "gemm_parts.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int NT_LDS_TILE = BM * BK;  // elements per operand per buffer
+constexpr int BK = 64;
 
-__device__ __forceinline__ int swz_off(int row, int chunk) {  // element offset inside a [128][64] bf16 tile
+__device__ __forceinline__ int swz_off(int row, int chunk) {  // element offset inside a [rows][64] bf16 tile
   return row * BK + ((chunk ^ (row & 7)) << 3);
 }
 
-__global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
-                                                           const bf16_t* __restrict__ Bw, int Np, long M, int K,
-                                                           vkas_epilogue e) {
-  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 2 * NT_LDS_TILE];  // [buf][A|B][128][64] = 64 KiB
+// WM x WN waves, each owning TM x TN 16x16 MFMA tiles: block tile = (WM*TM*16) x (WN*TN*16), BK = 64.
+// Instantiated as 128x128 (4 waves), 256x128, 256x192 and 256x224 (8 waves, 2 per SIMD): the wide tiles cut
+// the zero-padding waste on N = 192..200 (head convs) and raise the MFMA : LDS-traffic ratio.
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
+                                                                  const bf16_t* __restrict__ Bw, int Np, long M, int K,
+                                                                  vkas_epilogue e) {
+  constexpr int NTHR = WM * WN * 64;
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int RSTEP = NTHR / 8;                   // rows covered by one staging pass
+  constexpr int ACH = BM / RSTEP;                   // A chunks per thread
+  constexpr int BCH = (BN + RSTEP - 1) / RSTEP;     // B chunks per thread (last one guarded)
+  static_assert(BM % RSTEP == 0, "A tile must be covered by whole staging passes");
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (BM + BN) * BK];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const long m0 = (long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
 
-  // staging role: chunk column cc (8 elements), rows sr + 32*i
+  // staging role: chunk column cc (8 elements), rows sr + RSTEP*i
   const int cc = tid & 7;
   const int sr = tid >> 3;
-  int a_by[4], a_y[4], a_x[4];  // b*Hin, oy*stride-pad, ox*stride-pad ; a_by < 0 => row out of range
-  const bf16_t* b_ptr[4];
-  bool b_ok[4];
+  int a_by[ACH], a_y[ACH], a_x[ACH];  // b*Hin, oy*stride-pad, ox*stride-pad ; a_by < 0 => row out of range
+  const bf16_t* b_ptr[BCH];
+  bool b_ok[BCH];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const RowCoord rc = decode_row(m0 + sr + 32 * i, M, g);
+  for (int i = 0; i < ACH; ++i) {
+    const RowCoord rc = decode_row(m0 + sr + RSTEP * i, M, g);
     a_by[i] = rc.ok ? rc.b * g.Hin : -1;
     a_y[i] = rc.oy * g.stride - g.pad;
     a_x[i] = rc.ox * g.stride - g.pad;
-    const int n = n0 + sr + 32 * i;
-    b_ok[i] = n < Np;
+  }
+#pragma unroll
+  for (int i = 0; i < BCH; ++i) {
+    const int r = sr + RSTEP * i;
+    const int n = n0 + r;
+    b_ok[i] = r < BN && n < Np;
     b_ptr[i] = Bw + (long)(b_ok[i] ? n : 0) * K;
   }
   // running decode of this thread's k chunk: k = kt*BK + cc*8 -> (ky, kx, c)
@@ -55,20 +70,23 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const bf16_t* __restr
     if (++kx == g.KW) { kx = 0; ++ky; }
   }
 
-  bf16x8 ra[4], rb[4];
+  bf16x8 ra[ACH], rb[BCH];
   auto load_tile = [&]() {
     const bool k_ok = kcur < K;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ACH; ++i) {
       bf16x8 va = {0, 0, 0, 0, 0, 0, 0, 0};
-      bf16x8 vb = {0, 0, 0, 0, 0, 0, 0, 0};
       const int iy = a_y[i] + ky, ix = a_x[i] + kx;
       if (k_ok && a_by[i] >= 0 && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win) {
         const long off = ((long)(a_by[i] + iy) * g.Win + ix) * (long)g.ldx + c_in;
         va = *reinterpret_cast<const bf16x8*>(x + off);
       }
-      if (k_ok && b_ok[i]) vb = *reinterpret_cast<const bf16x8*>(b_ptr[i] + kcur);
       ra[i] = va;
+    }
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+      bf16x8 vb = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (k_ok && b_ok[i]) vb = *reinterpret_cast<const bf16x8*>(b_ptr[i] + kcur);
       rb[i] = vb;
     }
     // advance to the next K tile
@@ -80,21 +98,22 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const bf16_t* __restr
     }
   };
   auto store_tile = [&](int buf) {
-    bf16_t* As = lds + buf * 2 * NT_LDS_TILE;
-    bf16_t* Bs = As + NT_LDS_TILE;
+    bf16_t* As = lds + buf * (BM + BN) * BK;
+    bf16_t* Bs = As + BM * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = sr + 32 * i;
-      *reinterpret_cast<bf16x8*>(As + swz_off(row, cc)) = ra[i];
-      *reinterpret_cast<bf16x8*>(Bs + swz_off(row, cc)) = rb[i];
+    for (int i = 0; i < ACH; ++i) *reinterpret_cast<bf16x8*>(As + swz_off(sr + RSTEP * i, cc)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+      const int row = sr + RSTEP * i;
+      if (BN % RSTEP == 0 || row < BN) *reinterpret_cast<bf16x8*>(Bs + swz_off(row, cc)) = rb[i];
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = (K + BK - 1) / BK;
   load_tile();
@@ -106,22 +125,21 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const bf16_t* __restr
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_tile();
-    const bf16_t* As = lds + buf * 2 * NT_LDS_TILE;
-    const bf16_t* Bs = As + NT_LDS_TILE;
+    const bf16_t* As = lds + buf * (BM + BN) * BK;
+    const bf16_t* Bs = As + BM * BK;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 fa[4], fb[4];
+      bf16x8 fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ra_ = wm * 64 + i * 16 + frow;
-        const int rb_ = wn * 64 + i * 16 + frow;
-        fa[i] = *reinterpret_cast<const bf16x8*>(As + swz_off(ra_, s * 4 + fchunk));
-        fb[i] = *reinterpret_cast<const bf16x8*>(Bs + swz_off(rb_, s * 4 + fchunk));
-      }
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const bf16x8*>(As + swz_off(wm * TM * 16 + i * 16 + frow, s * 4 + fchunk));
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < TN; ++j)
+        fb[j] = *reinterpret_cast<const bf16x8*>(Bs + swz_off(wn * TN * 16 + j * 16 + frow, s * 4 + fchunk));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) store_tile(buf ^ 1);
@@ -130,12 +148,12 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const bf16_t* __restr
 
   // epilogue: lane holds D^T rows n = (lane>>4)*4 + r, col m = lane&15 of each 16x16 tile
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long m = m0 + wm * 64 + i * 16 + (lane & 15);
+  for (int i = 0; i < TM; ++i) {
+    const long m = m0 + wm * TM * 16 + i * 16 + (lane & 15);
     if (m >= M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * TN * 16 + j * 16 + (lane >> 4) * 4;
       if (n >= Np) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       epi_store4<bf16_t>(e, m, n, v);
@@ -144,15 +162,15 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const bf16_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
-constexpr int TN_ROWS = 64;         // reduction rows per iteration
-constexpr int TN_LD = 128 + 16;     // padded row (elements): 288 B, keeps the transposing reads conflict free
-constexpr int TN_TILE = TN_ROWS * TN_LD;
+constexpr int TN_ROWS = 64;  // reduction rows per iteration
 
+// k-permuted transposed fragment: elements 0..3 <- rows mbase + 4g + {0..3}, elements 4..7 <- rows mbase + 16 + 4g + {0..3}
+// (the same permutation is used for both MFMA operands, so the sum over k is unchanged)
+template <int LD>
 __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int mbase, int colbase, int lane) {
-  // k-permuted fragment: elements 0..3 <- rows mbase + 4g + {0..3}, elements 4..7 <- rows mbase + 16 + 4g + {0..3}
   const int g4 = lane >> 4, idx = lane & 15, q = idx >> 2, p = idx & 3;
-  const bf16_t* a0 = tile + (mbase + 4 * g4 + q) * TN_LD + colbase + 4 * p;
-  const bf16_t* a1 = a0 + 16 * TN_LD;
+  const bf16_t* a0 = tile + (mbase + 4 * g4 + q) * LD + colbase + 4 * p;
+  const bf16_t* a1 = a0 + 16 * LD;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
   union { struct { s16x4 l, h; } s; bf16x8 v; } u;
@@ -161,62 +179,88 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int mbase, int col
   return u.v;
 }
 
-__global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
-                                                           const bf16_t* __restrict__ dy, long lddy, int Np, long M,
-                                                           int K, long rows_per_split, float* __restrict__ gw) {
-  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 2 * TN_TILE];  // [buf][dy|x][64][144] = 72 KiB
+// gw[n][k] += sum_m dy[m][n] * A(m,k).  WN x WK waves, each TNn x TK MFMA tiles: the block owns (WN*TNn*16) output
+// channels x (WK*TK*16) K columns and walks its M split 64 rows at a time.  LDS tiles stay [row][col] with rows
+// padded by 16 elements (row pitch = odd multiple of 32 B => the 8 rows a half-wave touches in one transposing
+// read sit on distinct bank groups).
+template <int WN, int WK, int TNn, int TK>
+__global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
+                                                                  const bf16_t* __restrict__ dy, long lddy, int Np,
+                                                                  long M, int K, long rows_per_split,
+                                                                  float* __restrict__ gw) {
+  constexpr int NTHR = WN * WK * 64;
+  constexpr int BNn = WN * TNn * 16, BKc = WK * TK * 16;
+  constexpr int LDD = BNn + 16, LDX = BKc + 16;
+  static_assert((BNn / 16) % 2 == 0 && (BKc / 16) % 2 == 0, "row pitch must be an odd multiple of 32 bytes");
+  constexpr int CPRD = BNn / 8, CPRX = BKc / 8;           // 16-byte chunks per row
+  constexpr int DCH = (TN_ROWS * CPRD + NTHR - 1) / NTHR;  // dy chunks per thread (last guarded)
+  constexpr int XSTEP = NTHR / CPRX;                       // rows between a thread's x chunks
+  constexpr int XCH = TN_ROWS / XSTEP;                     // x chunks per thread
+  static_assert(NTHR % CPRX == 0 && TN_ROWS % XSTEP == 0, "x tile must be covered by whole staging passes");
+  constexpr int TILE = TN_ROWS * (LDD + LDX);
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * TILE];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wn = wave >> 1, wk = wave & 1;
-  const int n0 = blockIdx.x * 128;
-  const int kb = blockIdx.y * 128;
+  const int wn = wave / WK, wk = wave % WK;
+  const int n0 = blockIdx.x * BNn;
+  const int kb = blockIdx.y * BKc;
   const long mbeg = (long)blockIdx.z * rows_per_split;
   const long mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
 
-  // staging role: chunk column cc (0..15), rows sr + 16*i (i = 0..3)
-  const int cc = tid & 15;
-  const int sr = tid >> 4;
-  const int nn = n0 + cc * 8;
-  const bool n_ok = nn < Np;
-  const int k = kb + cc * 8;
+  // dy staging: chunk index tid + NTHR*i -> (row, col)
+  int d_row[DCH], d_lds[DCH];
+  const bf16_t* d_ptr[DCH];
+  bool d_ok[DCH];
+#pragma unroll
+  for (int i = 0; i < DCH; ++i) {
+    const int idx = tid + NTHR * i;
+    const int row = idx / CPRD, col = idx - row * CPRD;
+    d_row[i] = row;
+    d_ok[i] = row < TN_ROWS && n0 + col * 8 < Np;
+    d_lds[i] = (row < TN_ROWS ? row : 0) * LDD + col * 8;
+    d_ptr[i] = dy + (mbeg + (row < TN_ROWS ? row : 0)) * lddy + n0 + col * 8;
+  }
+  // x staging: fixed chunk column -> fixed tap (ky, kx) and channel offset; rows xr + XSTEP*i
+  const int xc = tid % CPRX;
+  const int xr = tid / CPRX;
+  const int k = kb + xc * 8;
   const bool k_ok = k < K;
-  int ky = 0, kx = 0, c_in = 0;
+  int kyo = 0, kxo = 0, c_in = 0;
   if (k_ok) {
     const int tap = k / g.Cp;
     c_in = k - tap * g.Cp;
-    ky = tap / g.KW;
-    kx = tap - ky * g.KW;
+    const int ky = tap / g.KW;
+    kyo = ky - g.pad;
+    kxo = tap - ky * g.KW - g.pad;
   }
-
-  // running (b, oy, ox) of the 4 rows this thread stages; advanced by TN_ROWS per iteration without divisions
-  int r_b[4], r_y[4], r_x[4];
+  int r_b[XCH], r_y[XCH], r_x[XCH];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const RowCoord rc = decode_row(mbeg + sr + 16 * i, M, g);
+  for (int i = 0; i < XCH; ++i) {
+    const RowCoord rc = decode_row(mbeg + xr + XSTEP * i, M, g);
     r_b[i] = rc.b;
     r_y[i] = rc.oy;
     r_x[i] = rc.ox;
   }
-  const int kyo = ky - g.pad, kxo = kx - g.pad;
 
-  bf16x8 rd[4], rx[4];
-  auto load_tile = [&](long mc) {
+  bf16x8 rd[DCH], rx[XCH];
+  long mcur = mbeg;
+  auto load_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long m = mc + sr + 16 * i;
+    for (int i = 0; i < DCH; ++i) {
       bf16x8 vd = {0, 0, 0, 0, 0, 0, 0, 0};
-      bf16x8 vx = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (m < mend) {
-        if (n_ok) vd = *reinterpret_cast<const bf16x8*>(dy + m * lddy + nn);
-        const int iy = r_y[i] * g.stride + kyo, ix = r_x[i] * g.stride + kxo;
-        if (k_ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win)
-          vx = *reinterpret_cast<const bf16x8*>(x + (((long)r_b[i] * g.Hin + iy) * g.Win + ix) * (long)g.ldx + c_in);
-      }
+      if (d_ok[i] && mcur + d_row[i] < mend) vd = *reinterpret_cast<const bf16x8*>(d_ptr[i]);
       rd[i] = vd;
+      d_ptr[i] += (long)TN_ROWS * lddy;
+    }
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      bf16x8 vx = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int iy = r_y[i] * g.stride + kyo, ix = r_x[i] * g.stride + kxo;
+      if (k_ok && mcur + xr + XSTEP * i < mend && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win)
+        vx = *reinterpret_cast<const bf16x8*>(x + (((long)r_b[i] * g.Hin + iy) * g.Win + ix) * (long)g.ldx + c_in);
       rx[i] = vx;
-      // advance this row by TN_ROWS output pixels
-      r_x[i] += TN_ROWS;
+      r_x[i] += TN_ROWS;  // advance this row by TN_ROWS output pixels, no divisions
       while (r_x[i] >= g.Wout) {
         r_x[i] -= g.Wout;
         if (++r_y[i] == g.Hout) {
@@ -225,48 +269,47 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const bf16_t* __restr
         }
       }
     }
+    mcur += TN_ROWS;
   };
   auto store_tile = [&](int buf) {
-    bf16_t* Ds = lds + buf * 2 * TN_TILE;
-    bf16_t* Xs = Ds + TN_TILE;
+    bf16_t* Ds = lds + buf * TILE;
+    bf16_t* Xs = Ds + TN_ROWS * LDD;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = sr + 16 * i;
-      *reinterpret_cast<bf16x8*>(Ds + row * TN_LD + cc * 8) = rd[i];
-      *reinterpret_cast<bf16x8*>(Xs + row * TN_LD + cc * 8) = rx[i];
-    }
+    for (int i = 0; i < DCH; ++i)
+      if ((TN_ROWS * CPRD) % NTHR == 0 || tid + NTHR * i < TN_ROWS * CPRD) *reinterpret_cast<bf16x8*>(Ds + d_lds[i]) = rd[i];
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) *reinterpret_cast<bf16x8*>(Xs + (xr + XSTEP * i) * LDX + xc * 8) = rx[i];
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[TNn][TK];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TNn; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TK; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const long nrows = mend - mbeg;
   const int nit = (int)((nrows + TN_ROWS - 1) / TN_ROWS);
   if (nit > 0) {
-    load_tile(mbeg);
+    load_tile();
     store_tile(0);
   }
   __syncthreads();
   for (int it = 0; it < nit; ++it) {
     const int buf = it & 1;
-    if (it + 1 < nit) load_tile(mbeg + (long)(it + 1) * TN_ROWS);
-    const bf16_t* Ds = lds + buf * 2 * TN_TILE;
-    const bf16_t* Xs = Ds + TN_TILE;
+    if (it + 1 < nit) load_tile();
+    const bf16_t* Ds = lds + buf * TILE;
+    const bf16_t* Xs = Ds + TN_ROWS * LDD;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 fd[4], fx[4];
+      bf16x8 fd[TNn], fx[TK];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fd[i] = tr_frag(Ds, s * 32, wn * 64 + i * 16, lane);
-        fx[i] = tr_frag(Xs, s * 32, wk * 64 + i * 16, lane);
-      }
+      for (int i = 0; i < TNn; ++i) fd[i] = tr_frag<LDD>(Ds, s * 32, wn * TNn * 16 + i * 16, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < TK; ++j) fx[j] = tr_frag<LDX>(Xs, s * 32, wk * TK * 16 + j * 16, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < TNn; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[i], fx[j], acc[i][j], 0, 0, 0);
     }
     if (it + 1 < nit) store_tile(buf ^ 1);
@@ -274,14 +317,14 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const bf16_t* __restr
   }
   // D[row = n_local][col = k_local]: lane holds col = lane&15, rows (lane>>4)*4 + r
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < TNn; ++i) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int kk = kb + wk * 64 + j * 16 + (lane & 15);
+    for (int j = 0; j < TK; ++j) {
+      const int kk = kb + wk * TK * 16 + j * 16 + (lane & 15);
       if (kk >= K) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4 + r;
+        const int n = n0 + wn * TNn * 16 + i * 16 + (lane >> 4) * 4 + r;
         if (n < Np) atomicAdd(gw + (long)n * K + kk, acc[i][j][r]);
       }
     }
@@ -290,24 +333,52 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const bf16_t* __restr
 
 }  // namespace
 
+template <int WM, int WN, int TM, int TN>
+static void launch_nt(const void* x, const vkas_conv_geom* g, const void* Bw, int Np, long M, int K,
+                      const vkas_epilogue* e, hipStream_t st) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  dim3 grid((unsigned)vkas_cdiv(M, BM), (unsigned)vkas_cdiv(Np, BN));
+  gemm_nt_mfma_kernel<WM, WN, TM, TN><<<grid, WM * WN * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)Bw, Np, M, K, *e);
+}
+
 int vkas_gemm_nt_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* Bw, int Np, const vkas_epilogue* e,
                            hipStream_t st) {
   const long M = (long)g->B * g->Hout * g->Wout;
   const int K = g->KH * g->KW * g->Cp;
   if (M == 0) return VKAS_OK;
-  dim3 grid((unsigned)vkas_cdiv(M, BM), (unsigned)vkas_cdiv(Np, BN));
-  gemm_nt_mfma_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)Bw, Np, M, K, *e);
+  // tile choice: 256-row tiles once there is enough work to fill the chip with them; N extent = the candidate
+  // with the least zero padding (ties -> wider tile, fewer re-reads of A)
+  static const int force = getenv("VKAS_NT_TILE") ? atoi(getenv("VKAS_NT_TILE")) : 0;
+  int bn = 128;
+  bool big = M >= 65536;
+  if (force) {
+    big = force != 1;
+    bn = force == 1 ? 128 : force;
+  } else if (big) {
+    long best = -1;
+    const int cand[3] = {224, 192, 128};
+    for (int c = 0; c < 3; ++c) {
+      const long padded = vkas_cdiv(Np, cand[c]) * cand[c];
+      if (best < 0 || padded < best) {
+        best = padded;
+        bn = cand[c];
+      }
+    }
+  }
+  if (!big) launch_nt<2, 2, 4, 4>(x, g, Bw, Np, M, K, e, st);
+  else if (bn == 224) launch_nt<4, 2, 4, 7>(x, g, Bw, Np, M, K, e, st);
+  else if (bn == 192) launch_nt<4, 2, 4, 6>(x, g, Bw, Np, M, K, e, st);
+  else launch_nt<4, 2, 4, 4>(x, g, Bw, Np, M, K, e, st);
   VKAS_LAUNCH_CHECK("gemm_nt_mfma");
   return VKAS_OK;
 }
 
-int vkas_gemm_tn_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
-                           hipStream_t st) {
-  const long M = (long)g->B * g->Hout * g->Wout;
-  const int K = g->KH * g->KW * g->Cp;
-  if (M == 0) return VKAS_OK;
-  const long tiles = vkas_cdiv(Np, 128) * vkas_cdiv(K, 128);
-  long splits = vkas_cdiv(1024, tiles);
+template <int WN, int WK, int TNn, int TK>
+static void launch_tn(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, long M, int K, float* gw,
+                      hipStream_t st) {
+  constexpr int BNn = WN * TNn * 16, BKc = WK * TK * 16;
+  const long tiles = vkas_cdiv(Np, BNn) * vkas_cdiv(K, BKc);
+  long splits = vkas_cdiv(768, tiles);
   const long max_splits = vkas_cdiv(M, 8 * TN_ROWS);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -315,8 +386,23 @@ int vkas_gemm_tn_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* d
   long rows = vkas_cdiv(M, splits);
   rows = vkas_cdiv(rows, TN_ROWS) * TN_ROWS;
   splits = vkas_cdiv(M, rows);
-  dim3 grid((unsigned)vkas_cdiv(Np, 128), (unsigned)vkas_cdiv(K, 128), (unsigned)splits);
-  gemm_tn_mfma_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy, Np, M, K, rows, gw);
+  dim3 grid((unsigned)vkas_cdiv(Np, BNn), (unsigned)vkas_cdiv(K, BKc), (unsigned)splits);
+  gemm_tn_mfma_kernel<WN, WK, TNn, TK><<<grid, WN * WK * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy, Np, M,
+                                                                     K, rows, gw);
+}
+
+int vkas_gemm_tn_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
+                           hipStream_t st) {
+  const long M = (long)g->B * g->Hout * g->Wout;
+  const int K = g->KH * g->KW * g->Cp;
+  if (M == 0) return VKAS_OK;
+  // 224 x 256 tiles (8 waves) when that wastes less of the N extent than 128-wide tiles and K is wide enough
+  static const int force = getenv("VKAS_TN_TILE") ? atoi(getenv("VKAS_TN_TILE")) : 0;
+  const long pad224 = vkas_cdiv(Np, 224) * 224, pad128 = vkas_cdiv(Np, 128) * 128;
+  bool wide = M >= 65536 && K >= 256 && pad224 <= pad128;
+  if (force) wide = force == 224;
+  if (wide) launch_tn<2, 4, 7, 4>(x, g, dy, lddy, Np, M, K, gw, st);
+  else launch_tn<2, 2, 4, 4>(x, g, dy, lddy, Np, M, K, gw, st);
   VKAS_LAUNCH_CHECK("gemm_tn_mfma");
   return VKAS_OK;
 }
