@@ -50,6 +50,8 @@ int vkas_check_epilogue(const char* who, const vkas_epilogue* e, int Np) {
   VKAS_CHECK(e && e->out, "%s: null output", who);
   VKAS_CHECK(vkas_aligned16(e->out) && e->ldo % 8 == 0, "%s: out misaligned (ldo=%ld)", who, e->ldo);
   VKAS_CHECK(e->mode >= VKAS_EPI_NONE && e->mode <= VKAS_EPI_PATCH, "%s: bad epilogue mode %d", who, e->mode);
+  VKAS_CHECK((!e->bias || vkas_aligned16(e->bias)) && (!e->colscale || vkas_aligned16(e->colscale)),
+             "%s: bias / colscale must be 16-byte aligned", who);
   if (e->mode != VKAS_EPI_PATCH) VKAS_CHECK(e->ldo >= Np, "%s: ldo=%ld < Np=%d", who, e->ldo, Np);
   if (e->mode == VKAS_EPI_GELU)
     VKAS_CHECK(e->out2 && vkas_aligned16(e->out2) && e->ldo2 >= Np && e->ldo2 % 8 == 0, "%s: GELU needs out2", who);

@@ -146,18 +146,37 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
     __syncthreads();
   }
 
-  // epilogue: lane holds D^T rows n = (lane>>4)*4 + r, col m = lane&15 of each 16x16 tile
+  // epilogue: the accumulators (lane = 4 consecutive channels of one pixel) go through LDS one wave-row at a time
+  // so that every global access of the fused epilogue is a coalesced 16-byte piece of an output row.
+  constexpr int EP = BN + 4;            // fp32 row pitch: pitch % 32 == 4 keeps the 16-byte writes conflict free
+  constexpr int ER = TM * 16;           // rows per pass
+  constexpr int VPR = BN / 8;           // 8-channel vectors per row
+  static_assert(ER * EP * 4 <= 2 * (BM + BN) * BK * 2, "epilogue staging must fit the tile buffers");
+  float* stage = reinterpret_cast<float*>(lds);
+#pragma unroll 1
+  for (int pass = 0; pass < WM; ++pass) {
+    if (wm == pass) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const long m = m0 + wm * TM * 16 + i * 16 + (lane & 15);
-    if (m >= M) continue;
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * TN * 16 + j * 16 + (lane >> 4) * 4;
-      if (n >= Np) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      epi_store4<bf16_t>(e, m, n, v);
+        for (int j = 0; j < TN; ++j)
+          *reinterpret_cast<f32x4*>(stage + (i * 16 + (lane & 15)) * EP + wn * TN * 16 + j * 16 + (lane >> 4) * 4) =
+              acc[i][j];
     }
+    __syncthreads();
+    for (int t = tid; t < ER * VPR; t += NTHR) {
+      const int row = t / VPR, c8 = t - row * VPR;
+      const long m = m0 + pass * ER + row;
+      const int n = n0 + c8 * 8;
+      if (m < M && n < Np) {
+        float v[8];
+        const float4 lo = *reinterpret_cast<const float4*>(stage + row * EP + c8 * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(stage + row * EP + c8 * 8 + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        epi_store8<bf16_t>(e, m, n, v);
+      }
+    }
+    __syncthreads();
   }
 }
 

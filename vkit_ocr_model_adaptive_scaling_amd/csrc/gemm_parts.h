@@ -95,5 +95,75 @@ __device__ __forceinline__ void epi_store4(const vkas_epilogue& e, long m, int n
   }
 }
 
+// 8 consecutive output columns n..n+7 of row m (n % 8 == 0): the coalesced form used by the MFMA kernels, whose
+// accumulators are first transposed through LDS so that a lane owns a 16-byte piece of an output row.
+template <typename T>
+__device__ __forceinline__ void epi_store8(const vkas_epilogue& e, long m, int n, float* v) {
+  if (e.bias) {
+    float b[8];
+    load8(e.bias + n, b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += b[i];
+  }
+  T* out = reinterpret_cast<T*>(e.out);
+  switch (e.mode) {
+    case VKAS_EPI_NONE:
+      store8(out + m * e.ldo + n, v);
+      break;
+    case VKAS_EPI_GELU: {
+      store8(out + m * e.ldo + n, v);
+      float gv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) gv[i] = gelu_f(v[i]);
+      store8(reinterpret_cast<T*>(e.out2) + m * e.ldo2 + n, gv);
+      break;
+    }
+    case VKAS_EPI_SCALE_RES: {
+      if (e.out2) store8(reinterpret_cast<T*>(e.out2) + m * e.ldo2 + n, v);
+      float r[8], cs[8];
+      load8(reinterpret_cast<const T*>(e.aux) + m * e.ldaux + n, r);
+      load8(e.colscale + n, cs);
+      const float rs = e.rowscale ? e.rowscale[m / e.rows_per_image] : 1.0f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) r[i] += rs * cs[i] * v[i];
+      store8(out + m * e.ldo + n, r);
+      break;
+    }
+    case VKAS_EPI_DGELU: {
+      float h[8];
+      load8(reinterpret_cast<const T*>(e.aux) + m * e.ldaux + n, h);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] *= dgelu_f(h[i]);
+      store8(out + m * e.ldo + n, v);
+      break;
+    }
+    case VKAS_EPI_ADD: {
+      float r[8];
+      load8(reinterpret_cast<const T*>(e.aux) + m * e.ldaux + n, r);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += r[i];
+      store8(out + m * e.ldo + n, v);
+      break;
+    }
+    case VKAS_EPI_PATCH: {
+      const int tap = n / e.patch_Cp;
+      const int c = n - tap * e.patch_Cp;
+      const int ky = tap / e.patch;
+      const int kx = tap - ky * e.patch;
+      const int hw = e.patch_Hs * e.patch_Ws;
+      const int b = (int)(m / hw);
+      const int rem = (int)(m - (long)b * hw);
+      const int y = rem / e.patch_Ws;
+      const int x = rem - y * e.patch_Ws;
+      const long pix = ((long)b * e.patch_Hs * e.patch + (long)y * e.patch + ky) * ((long)e.patch_Ws * e.patch) +
+                       (long)x * e.patch + kx;
+      store8(out + pix * e.ldo + c, v);
+      break;
+    }
+    default:
+      break;
+  }
+}
+
 int vkas_check_geom(const char* who, const void* x, const vkas_conv_geom* g, int Np);
 int vkas_check_epilogue(const char* who, const vkas_epilogue* e, int Np);
