@@ -99,10 +99,11 @@ int vkas_nchw_f32_to_nhwc(const float* g, void* out, long ld, int B, int H, int 
 /* D[m][n] = epilogue( sum_k A(m,k) * Bw[n][k] ), A gathered from x by `g`; Bw (Np, K) packed `dtype`. */
 int vkas_conv_gemm_fwd(const void* x, const vkas_conv_geom* g, const void* Bw, int Np, const vkas_epilogue* epi,
                        int dtype, void* stream);
-/* wgrad: gw[n][k] (+)= sum_m dy[m][n] * A(m,k); gw (Np, K) fp32; `ws` >= vkas_conv_gemm_wgrad_ws_bytes().
- * gw must be zero-filled by the caller (the kernel accumulates split-M partials into it). */
+/* wgrad: gw[n][k] += sum_m dy[m][n] * A(m,k), gw (Np, K) fp32; optional fused bias gradient gb[n] += sum_m dy[m][n]
+ * (gb (Np) fp32 or NULL).  gw and gb must be zero-filled by the caller: the kernel adds split-M partials with
+ * fp32 atomics. */
 int vkas_conv_gemm_wgrad(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
-                         int dtype, void* stream);
+                         float* gb, int dtype, void* stream);
 /* column sums: out[n] (+)= sum_m y[m][n]   (bias gradients) */
 int vkas_colsum(const void* y, long ld, long M, int Np, float* out, int accumulate, float* ws, size_t ws_bytes,
                 int dtype, void* stream);

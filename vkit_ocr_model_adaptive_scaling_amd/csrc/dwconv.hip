@@ -272,6 +272,7 @@ extern "C" int vkas_dwconv7x7_wgrad(const void* x, long ldx, const void* dy, lon
     dwconv7x7_wgrad_kernel<T><<<grid, 256, 0, st>>>((const T*)x, ldx, (const T*)dy, lddy, ws, H, W, Cp, cslices);
   })
   VKAS_LAUNCH_CHECK("dwconv7x7_wgrad");
+  if (gb == gw + 49L * Cp) return vkas_colreduce_finalize(ws, P, 50 * Cp, 50 * Cp, gw, 0, st);  // one launch
   rc = vkas_colreduce_finalize(ws, P, 49 * Cp, 50 * Cp, gw, 0, st);
   if (rc) return rc;
   return vkas_colreduce_finalize(ws + 49L * Cp, P, Cp, 50 * Cp, gb, 0, st);

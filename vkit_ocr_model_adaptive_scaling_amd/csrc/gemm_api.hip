@@ -5,9 +5,9 @@
 #include "gemm_parts.h"
 
 int vkas_gemm_nt_simple(const void*, const vkas_conv_geom*, const void*, int, const vkas_epilogue*, int, hipStream_t);
-int vkas_gemm_tn_simple(const void*, const vkas_conv_geom*, const void*, long, int, float*, int, hipStream_t);
+int vkas_gemm_tn_simple(const void*, const vkas_conv_geom*, const void*, long, int, float*, float*, int, hipStream_t);
 int vkas_gemm_nt_mfma_bf16(const void*, const vkas_conv_geom*, const void*, int, const vkas_epilogue*, hipStream_t);
-int vkas_gemm_tn_mfma_bf16(const void*, const vkas_conv_geom*, const void*, long, int, float*, hipStream_t);
+int vkas_gemm_tn_mfma_bf16(const void*, const vkas_conv_geom*, const void*, long, int, float*, float*, hipStream_t);
 
 static thread_local char g_err[512] = "";
 
@@ -83,13 +83,13 @@ extern "C" int vkas_conv_gemm_fwd(const void* x, const vkas_conv_geom* g, const 
 }
 
 extern "C" int vkas_conv_gemm_wgrad(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np,
-                                    float* gw, int dtype, void* stream) {
+                                    float* gw, float* gb, int dtype, void* stream) {
   int rc = vkas_check_geom("vkas_conv_gemm_wgrad", x, g, Np);
   if (rc) return rc;
   VKAS_CHECK(dy && vkas_aligned16(dy) && lddy >= Np && lddy % 8 == 0, "vkas_conv_gemm_wgrad: bad dy (lddy=%ld)", lddy);
   VKAS_CHECK(gw, "vkas_conv_gemm_wgrad: null gw");
-  if (dtype == VKAS_BF16 && !force_simple()) return vkas_gemm_tn_mfma_bf16(x, g, dy, lddy, Np, gw, vkas_stream(stream));
-  return vkas_gemm_tn_simple(x, g, dy, lddy, Np, gw, dtype, vkas_stream(stream));
+  if (dtype == VKAS_BF16 && !force_simple()) return vkas_gemm_tn_mfma_bf16(x, g, dy, lddy, Np, gw, gb, vkas_stream(stream));
+  return vkas_gemm_tn_simple(x, g, dy, lddy, Np, gw, gb, dtype, vkas_stream(stream));
 }
 
 // ---- column sums ------------------------------------------------------------------------------------

@@ -206,7 +206,7 @@ template <int WN, int WK, int TNn, int TK>
 __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
                                                                   const bf16_t* __restrict__ dy, long lddy, int Np,
                                                                   long M, int K, long rows_per_split,
-                                                                  float* __restrict__ gw) {
+                                                                  float* __restrict__ gw, float* __restrict__ gb) {
   constexpr int NTHR = WN * WK * 64;
   constexpr int BNn = WN * TNn * 16, BKc = WK * TK * 16;
   constexpr int LDD = BNn + 16, LDX = BKc + 16;
@@ -305,6 +305,11 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
   for (int i = 0; i < TNn; ++i)
 #pragma unroll
     for (int j = 0; j < TK; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // bias gradient = column sums of dy: the first K block's wk == 0 waves add up the dy fragments they already hold
+  const bool do_bias = gb != nullptr && blockIdx.y == 0 && wk == 0;
+  float bsum[TNn];
+#pragma unroll
+  for (int i = 0; i < TNn; ++i) bsum[i] = 0.f;
 
   const long nrows = mend - mbeg;
   const int nit = (int)((nrows + TN_ROWS - 1) / TN_ROWS);
@@ -330,6 +335,12 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
 #pragma unroll
         for (int j = 0; j < TK; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[i], fx[j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < TNn; ++i)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) bsum[i] += (float)fd[i][q];
+      }
     }
     if (it + 1 < nit) store_tile(buf ^ 1);
     __syncthreads();
@@ -346,6 +357,16 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
         const int n = n0 + wn * TNn * 16 + i * 16 + (lane >> 4) * 4 + r;
         if (n < Np) atomicAdd(gw + (long)n * K + kk, acc[i][j][r]);
       }
+    }
+  }
+  if (do_bias) {  // lanes l, l^16, l^32, l^48 hold different rows of the same column
+#pragma unroll
+    for (int i = 0; i < TNn; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int n = n0 + wn * TNn * 16 + i * 16 + (lane & 15);
+      if (lane < 16 && n < Np) atomicAdd(gb + n, v);
     }
   }
 }
@@ -394,7 +415,7 @@ int vkas_gemm_nt_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* B
 
 template <int WN, int WK, int TNn, int TK>
 static void launch_tn(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, long M, int K, float* gw,
-                      hipStream_t st) {
+                      float* gb, hipStream_t st) {
   constexpr int BNn = WN * TNn * 16, BKc = WK * TK * 16;
   const long tiles = vkas_cdiv(Np, BNn) * vkas_cdiv(K, BKc);
   long splits = vkas_cdiv(768, tiles);
@@ -407,21 +428,34 @@ static void launch_tn(const void* x, const vkas_conv_geom* g, const void* dy, lo
   splits = vkas_cdiv(M, rows);
   dim3 grid((unsigned)vkas_cdiv(Np, BNn), (unsigned)vkas_cdiv(K, BKc), (unsigned)splits);
   gemm_tn_mfma_kernel<WN, WK, TNn, TK><<<grid, WN * WK * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy, Np, M,
-                                                                     K, rows, gw);
+                                                                     K, rows, gw, gb);
 }
 
 int vkas_gemm_tn_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
-                           hipStream_t st) {
+                           float* gb, hipStream_t st) {
   const long M = (long)g->B * g->Hout * g->Wout;
   const int K = g->KH * g->KW * g->Cp;
   if (M == 0) return VKAS_OK;
-  // 224 x 256 tiles (8 waves) when that wastes less of the N extent than 128-wide tiles and K is wide enough
+  // 8-wave tiles (224 or 192 output channels x 256 K columns) when there is enough work and K is wide enough; the
+  // N extent is the candidate with the least zero padding
   static const int force = getenv("VKAS_TN_TILE") ? atoi(getenv("VKAS_TN_TILE")) : 0;
-  const long pad224 = vkas_cdiv(Np, 224) * 224, pad128 = vkas_cdiv(Np, 128) * 128;
-  bool wide = M >= 65536 && K >= 256 && pad224 <= pad128;
-  if (force) wide = force == 224;
-  if (wide) launch_tn<2, 4, 7, 4>(x, g, dy, lddy, Np, M, K, gw, st);
-  else launch_tn<2, 2, 4, 4>(x, g, dy, lddy, Np, M, K, gw, st);
+  int bn = 128;
+  if (force) {
+    bn = force;
+  } else if (M >= 65536 && K >= 256) {
+    long best = vkas_cdiv(Np, 128) * 128;
+    const int cand[2] = {192, 224};
+    for (int c = 0; c < 2; ++c) {
+      const long padded = vkas_cdiv(Np, cand[c]) * cand[c];
+      if (padded <= best) {
+        best = padded;
+        bn = cand[c];
+      }
+    }
+  }
+  if (bn == 224) launch_tn<2, 4, 7, 4>(x, g, dy, lddy, Np, M, K, gw, gb, st);
+  else if (bn == 192) launch_tn<2, 4, 6, 4>(x, g, dy, lddy, Np, M, K, gw, gb, st);
+  else launch_tn<2, 2, 4, 4>(x, g, dy, lddy, Np, M, K, gw, gb, st);
   VKAS_LAUNCH_CHECK("gemm_tn_mfma");
   return VKAS_OK;
 }

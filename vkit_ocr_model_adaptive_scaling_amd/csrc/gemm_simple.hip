@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256) void gemm_nt_simple_kernel(const T* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_tn_simple_kernel(const T* __restrict__ x, vkas_conv_geom g,
                                                              const T* __restrict__ dy, long lddy, int Np, long M,
-                                                             int K, long rows_per_split, float* __restrict__ gw) {
+                                                             int K, long rows_per_split, float* __restrict__ gw,
+                                                             float* __restrict__ gb) {
   __shared__ __attribute__((aligned(16))) float Ds[TK][LDT];  // [m][n]
   __shared__ __attribute__((aligned(16))) float Xs[TK][LDT];  // [m][k]
   const int tid = threadIdx.x;
@@ -109,6 +110,8 @@ __global__ __launch_bounds__(256) void gemm_tn_simple_kernel(const T* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
 
+  const bool do_bias = gb != nullptr && blockIdx.y == 0 && tx == 0;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   for (long mc = mbeg; mc < mend; mc += TK) {
     const long m = mc + mi;
     float dv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -134,8 +137,17 @@ __global__ __launch_bounds__(256) void gemm_tn_simple_kernel(const T* __restrict
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(aa[i], bb[j], acc[i][j]);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bsum[i] += aa[i];
+      }
     }
     __syncthreads();
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (n0 + ty * 4 + i < Np) atomicAdd(gb + n0 + ty * 4 + i, bsum[i]);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -165,7 +177,7 @@ int vkas_gemm_nt_simple(const void* x, const vkas_conv_geom* g, const void* Bw, 
 }
 
 int vkas_gemm_tn_simple(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
-                        int dtype, hipStream_t st) {
+                        float* gb, int dtype, hipStream_t st) {
   const long M = (long)g->B * g->Hout * g->Wout;
   const int K = g->KH * g->KW * g->Cp;
   if (M == 0) return VKAS_OK;
@@ -180,7 +192,7 @@ int vkas_gemm_tn_simple(const void* x, const vkas_conv_geom* g, const void* dy, 
   splits = vkas_cdiv(M, rows);
   dim3 grid((unsigned)vkas_cdiv(Np, TS), (unsigned)vkas_cdiv(K, TS), (unsigned)splits);
   VKAS_DISPATCH_DTYPE(dtype, "gemm_tn_simple", {
-    gemm_tn_simple_kernel<T><<<grid, 256, 0, st>>>((const T*)x, *g, (const T*)dy, lddy, Np, M, K, rows, gw);
+    gemm_tn_simple_kernel<T><<<grid, 256, 0, st>>>((const T*)x, *g, (const T*)dy, lddy, Np, M, K, rows, gw, gb);
   })
   VKAS_LAUNCH_CHECK("gemm_tn_simple");
   return VKAS_OK;

@@ -307,6 +307,7 @@ extern "C" int vkas_layernorm_bwd(const void* x, long ldx, const float* gamma, c
                                                               (T*)dx, lddx, ws, M, C, Cp, G, act_gelu, rpb);
   })
   VKAS_LAUNCH_CHECK("layernorm_bwd");
+  if (dbeta == dgamma + Cp) return vkas_colreduce_finalize(ws, P, 2 * Cp, 2 * Cp, dgamma, 0, st);  // one launch
   int rc = vkas_colreduce_finalize(ws, P, Cp, 2 * Cp, dgamma, 0, st);
   if (rc) return rc;
   return vkas_colreduce_finalize(ws + Cp, P, Cp, 2 * Cp, dbeta, 0, st);
@@ -339,6 +340,7 @@ extern "C" int vkas_scale_res_bwd(const void* dout, long lddo, const void* z, lo
                                                          rows_per_image, (T*)dz, lddz, ws, M, Cp, rpb);
   })
   VKAS_LAUNCH_CHECK("scale_res_bwd");
+  if (dbias == dscale + Cp) return vkas_colreduce_finalize(ws, P, 2 * Cp, 2 * Cp, dscale, 0, st);  // one launch
   int rc = vkas_colreduce_finalize(ws, P, Cp, 2 * Cp, dscale, 0, st);
   if (rc) return rc;
   return vkas_colreduce_finalize(ws + Cp, P, Cp, 2 * Cp, dbias, 0, st);

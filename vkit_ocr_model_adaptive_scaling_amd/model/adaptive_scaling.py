@@ -6,6 +6,7 @@ from typing import Dict, Mapping, Optional, Sequence, Tuple
 import attrs
 import torch
 from torch import nn
+from torch.nn import functional as F
 
 from .convnext import ConvNext
 from .fpn import FpnNeck, FpnHead
@@ -92,15 +93,26 @@ class AdaptiveScaling(nn.Module):
         return set_compute_dtype(self, dtype)
 
     def _run_heads(self, neck_feature: torch.Tensor, heads: Sequence[nn.Module]):
-        # every head of a pass reads the same neck feature: upsample it once (adaptive_scaling.py:150-152,163-170)
-        first = heads[0][0] if isinstance(heads[0], nn.Sequential) else heads[0]
-        up = first.upsample_act(neck_feature)
+        """All heads of a pass read the same neck feature (adaptive_scaling.py:150-152,163-170): upsample it once and
+        run their 3x3 convolutions as ONE implicit GEMM (output channels of the heads side by side, each padded to a
+        multiple of 8), then per-head LayerNorm+GELU on channel slices, projection, NCHW, Softplus."""
+        plain = [h[0] if isinstance(h, nn.Sequential) else h for h in heads]
+        up = plain[0].upsample_act(neck_feature)
+        convs, norms, projs = zip(*[h.conv_norm_proj() for h in plain])
+        w_parts, b_parts = [], []
+        for c in convs:
+            pad = ops.rup8(c.out_channels) - c.out_channels
+            w_parts.append(F.pad(c.weight, (0, 0, 0, 0, 0, 0, 0, pad)) if pad else c.weight)
+            b_parts.append(F.pad(c.bias, (0, pad)) if pad else c.bias)
+        z = ops.Conv.apply(up, torch.cat(w_parts, 0), torch.cat(b_parts, 0), 1, 1)
+        affine = []
+        for nm in norms:
+            affine.extend([nm.weight, nm.bias])
+        acts = ops.MultiLayerNorm.apply(z, True, *affine)
         outs = []
-        for h in heads:
-            if isinstance(h, nn.Sequential):
-                outs.append(h[1](h[0].forward_act(neck_feature, upsampled=up)))
-            else:
-                outs.append(h.forward_act(neck_feature, upsampled=up))
+        for h, hp, a, proj in zip(heads, plain, acts, projs):
+            y = ops.ToNchw.apply(ops.Conv.apply(a, proj.weight, proj.bias, 1, 0), hp.out_channels)
+            outs.append(h[1](y) if isinstance(h, nn.Sequential) else y)
         return tuple(outs)
 
     def forward_rough(self, x: torch.Tensor, drop_masks=None) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -93,6 +93,10 @@ class FpnHead(nn.Module):
         _init_kaiming(self)
         nn.init.constant_(self.step2_conv[1].bias, init_output_bias)  # fpn.py:191
 
+    def conv_norm_proj(self):
+        """(3x3 conv, its LayerNorm, the 1x1 projection) parameter holders."""
+        return self.step1_conv[0], self.step1_conv[2], self.step2_conv[1]
+
     def upsample_act(self, x: torch.Tensor) -> torch.Tensor:
         if self.upsampling_factor > 1:
             f = self.upsampling_factor

@@ -126,6 +126,10 @@ class UperNextHead(nn.Module):
         _init_trunc_normal(self)
         nn.init.constant_(self.step2_conv1x1[1].bias, init_output_bias)  # upernext.py:231
 
+    def conv_norm_proj(self):
+        """(3x3 conv, its LayerNorm, the 1x1 projection) parameter holders."""
+        return self.step1_conv3x3[0], self.step1_conv3x3[2], self.step2_conv1x1[1]
+
     def upsample_act(self, x: torch.Tensor) -> torch.Tensor:
         if self.upsampling_factor > 1:
             f = self.upsampling_factor

@@ -171,15 +171,19 @@ def _conv_gemm(x, geom, Bw, Np, out, mode, bias, out2, aux, colscale, rowscale, 
     return out
 
 
-def conv_wgrad(x: torch.Tensor, geom: ConvGeom, dy: torch.Tensor, Np: int, nk=None) -> torch.Tensor:
+def conv_wgrad(x: torch.Tensor, geom: ConvGeom, dy: torch.Tensor, Np: int, nk=None, with_bias: bool = False):
+    """Weight gradient in the packed (Np, K) layout; with_bias also returns the fused bias gradient (Np,): the two
+    live in one zero-filled buffer so a single memset covers both."""
     K = geom.KH * geom.KW * geom.Cp
-    gw = torch.zeros((Np * K,), dtype=_FLOAT, device=x.device)
+    buf = torch.zeros((Np * K + (Np if with_bias else 0),), dtype=_FLOAT, device=x.device)
+    gw = buf[:Np * K]
+    gb = buf[Np * K:] if with_bias else None
     M = geom.B * geom.Hout * geom.Wout
 
     def run():
-        check(lib.vkas_conv_gemm_wgrad(_p(x), ctypes.byref(geom), _p(dy), act_ld(dy), Np, _p(gw), _dt(x), _stream()),
-              'conv_gemm_wgrad')
-        return gw
+        check(lib.vkas_conv_gemm_wgrad(_p(x), ctypes.byref(geom), _p(dy), act_ld(dy), Np, _p(gw), _p(gb), _dt(x),
+                                       _stream()), 'conv_gemm_wgrad')
+        return (gw, gb) if with_bias else gw
     kind = 'gemm_tn_mfma' if x.dtype == torch.bfloat16 else 'gemm_tn_simple'
     N, Kl = nk if nk is not None else (Np, K)
     return _timed(kind, x, 2.0 * M * N * Kl, M, N, Kl, run)
@@ -218,8 +222,8 @@ def layernorm_bwd(x, gamma, beta, stats, dy, C: int, act_gelu: bool):
     B, H, W, Cp = x.shape
     M = B * H * W
     dx = new_act(B, H, W, Cp, x)
-    dg = torch.empty((Cp,), dtype=_FLOAT, device=x.device)
-    db = torch.empty((Cp,), dtype=_FLOAT, device=x.device)
+    dgb = torch.empty((2 * Cp,), dtype=_FLOAT, device=x.device)  # contiguous pair -> one finalize launch
+    dg, db = dgb[:Cp], dgb[Cp:]
     nbytes = lib.vkas_layernorm_bwd_ws_bytes(M, Cp)
     ws = _ws(nbytes, x.device)
     gamma, beta = pad_vector(gamma, Cp), pad_vector(beta, Cp)
@@ -315,8 +319,12 @@ class Conv(Function):
         B, Hin, Win, Cp = x.shape
         _, Hout, Wout, Np = dy.shape
         geom = _geom(B, Hin, Win, Hout, Wout, Cp, act_ld(x), KH, KW, stride, pad)
-        gw = unpack_wgrad(conv_wgrad(x, geom, dy, Np, nk=(N, C * KH * KW)), (N, C, KH, KW), Np, Cp).view(weight.shape)
-        gb = colsum(dy, N) if has_bias else None
+        if has_bias:
+            gwp, gbp = conv_wgrad(x, geom, dy, Np, nk=(N, C * KH * KW), with_bias=True)
+            gb = gbp[:N]
+        else:
+            gwp, gb = conv_wgrad(x, geom, dy, Np, nk=(N, C * KH * KW)), None
+        gw = unpack_wgrad(gwp, (N, C, KH, KW), Np, Cp).view(weight.shape)
         dx = None
         if need_input_grad and ctx.needs_input_grad[0]:
             if stride == 1:
@@ -355,6 +363,63 @@ class LayerNorm(Function):
         dx, dg, db = layernorm_bwd(x, gamma.contiguous(), beta.contiguous(), stats, as_act(dy), gamma.numel(),
                                    ctx.act_gelu)
         return dx, dg, db, None
+
+
+class MultiLayerNorm(Function):
+    """Per-head LayerNorm(+GELU) over channel slices of one wide activation.
+
+    The heads of a pass share their input, so their 3x3 convolutions run as ONE implicit GEMM whose output holds
+    every head's channels side by side (slice h = rup8(C_h) channels).  This op normalises each slice separately
+    (model/upernext.py:39-45 per head) and, in backward, writes each head's input gradient straight into its slice
+    of one gradient buffer, so the shared conv sees a single dy: no per-head dgrad tensors, no gradient adds."""
+
+    @staticmethod
+    def forward(ctx, x, act_gelu: bool, *affine):
+        _require_cuda(x)
+        x = as_act(x)
+        gammas, betas = affine[0::2], affine[1::2]
+        outs, stats, off = [], [], 0
+        for g, b in zip(gammas, betas):
+            C = g.numel()
+            Cp = rup8(C)
+            y, st = layernorm_fwd(x[..., off:off + Cp], g, b, C, act_gelu)
+            outs.append(y)
+            stats.append(st)
+            off += Cp
+        if off != x.shape[3]:
+            raise ValueError(f'MultiLayerNorm: slices cover {off} of {x.shape[3]} channels')
+        ctx.save_for_backward(x, *gammas, *betas, *stats)
+        ctx.n = len(gammas)
+        ctx.act_gelu = act_gelu
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        x, gammas, betas, stats = saved[0], saved[1:1 + n], saved[1 + n:1 + 2 * n], saved[1 + 2 * n:]
+        B, H, W, Ct = x.shape
+        dx = new_act(B, H, W, Ct, x)
+        grads, off = [], 0
+        M = B * H * W
+        for g, b, st, dy in zip(gammas, betas, stats, dys):
+            C = g.numel()
+            Cp = rup8(C)
+            dy = as_act(dy)
+            xs, dxs = x[..., off:off + Cp], dx[..., off:off + Cp]
+            dgb = torch.empty((2 * Cp,), dtype=_FLOAT, device=x.device)
+            nbytes = lib.vkas_layernorm_bwd_ws_bytes(M, Cp)
+            ws = _ws(nbytes, x.device)
+            gp, bp = pad_vector(g, Cp), pad_vector(b, Cp)
+            check(lib.vkas_layernorm_bwd(_p(xs), act_ld(xs), _p(gp), _p(bp), _p(st), _p(dy), act_ld(dy), _p(dxs),
+                                         act_ld(dxs), _p(dgb[:Cp]), _p(dgb[Cp:]), _p(ws), nbytes, M, C, Cp,
+                                         int(ctx.act_gelu), _dt(x), _stream()), 'layernorm_bwd')
+            grads.append((dgb[:C], dgb[Cp:Cp + C]))
+            off += Cp
+        flat = []
+        for dg, db in grads:
+            flat.extend([dg, db])
+        return (dx, None, *flat)
 
 
 class ConvNextLayer(Function):
@@ -412,8 +477,8 @@ class ConvNextLayer(Function):
         cs = pad_vector(block_scale, Cp)
         # out = x + rs*cs*z  ->  dz, d(block_scale), d(b2)
         dz = new_act(B, H, W, Cp, x)
-        dscale = torch.empty((Cp,), dtype=_FLOAT, device=dev)
-        db2 = torch.empty((Cp,), dtype=_FLOAT, device=dev)
+        dsb = torch.empty((2 * Cp,), dtype=_FLOAT, device=dev)
+        dscale, db2 = dsb[:Cp], dsb[Cp:]
         nbytes = lib.vkas_scale_res_bwd_ws_bytes(M, Cp)
         ws = _ws(nbytes, dev)
         check(lib.vkas_scale_res_bwd(_p(dout), act_ld(dout), _p(z), Cp, _p(cs), _p(rs), H * W, _p(dz), Cp, _p(dscale),
@@ -424,18 +489,19 @@ class ConvNextLayer(Function):
         dh = new_act(B, H, W, C4p, x)
         gd = _geom(B, H, W, H, W, Cp, Cp, 1, 1, 1, 0)
         conv_gemm(dz, gd, pack_conv_weight(w2, Cp, C4p, 1, x.dtype), C4p, dh, _lib.EPI_DGELU, aux=h)
-        # GEMM1: h = yn W1^T + b1
-        db1 = colsum(dh, C4)
+        # GEMM1: h = yn W1^T + b1 (bias gradient fused into the wgrad kernel)
         g1 = _geom(B, H, W, H, W, Cp, Cp, 1, 1, 1, 0)
-        gw1 = unpack_wgrad(conv_wgrad(yn, g1, dh, C4p), (C4, C, 1, 1), C4p, Cp).view(w1.shape)
+        gw1p, db1p = conv_wgrad(yn, g1, dh, C4p, with_bias=True)
+        db1 = db1p[:C4]
+        gw1 = unpack_wgrad(gw1p, (C4, C, 1, 1), C4p, Cp).view(w1.shape)
         dyn = new_act(B, H, W, Cp, x)
         gd1 = _geom(B, H, W, H, W, C4p, C4p, 1, 1, 1, 0)
         conv_gemm(dh, gd1, pack_conv_weight(w1, C4p, Cp, 1, x.dtype), Cp, dyn, _lib.EPI_NONE)
         # LayerNorm
         dy, dlg, dlb = layernorm_bwd(y, ln_g.contiguous(), ln_b.contiguous(), stats, dyn, C, False)
         # depthwise: wgrad, then dgrad (+ the residual path) in one kernel
-        gdw = torch.empty((49 * Cp,), dtype=_FLOAT, device=dev)
-        gdb = torch.empty((Cp,), dtype=_FLOAT, device=dev)
+        gdwb = torch.empty((50 * Cp,), dtype=_FLOAT, device=dev)
+        gdw, gdb = gdwb[:49 * Cp], gdwb[49 * Cp:]
         nbytes = lib.vkas_dwconv7x7_wgrad_ws_bytes(B, H, W, Cp)
         ws = _ws(nbytes, dev)
         check(lib.vkas_dwconv7x7_wgrad(_p(x), act_ld(x), _p(dy), Cp, _p(gdw), _p(gdb), _p(ws), nbytes, B, H, W, Cp, dt,
