@@ -418,7 +418,10 @@ static void launch_tn(const void* x, const vkas_conv_geom* g, const void* dy, lo
                       float* gb, hipStream_t st) {
   constexpr int BNn = WN * TNn * 16, BKc = WK * TK * 16;
   const long tiles = vkas_cdiv(Np, BNn) * vkas_cdiv(K, BKc);
-  long splits = vkas_cdiv(768, tiles);
+  // whole rounds of resident workgroups: 256 CUs x (1 block of 8 waves | 2 blocks of 4 waves) x 3 rounds, rounded
+  // DOWN so that the last round is not a nearly empty tail
+  const long resident = 256L * (WN * WK >= 8 ? 1 : 2);
+  long splits = (3 * resident) / tiles;
   const long max_splits = vkas_cdiv(M, 8 * TN_ROWS);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

@@ -26,7 +26,9 @@ static inline int pick_group(int nvec) {
   return g;
 }
 
-template <typename T, int MAXV>
+// R rows per lane group are in flight together (all loads issued before the first reduction): a single 16-byte
+// load per lane leaves the memory system mostly idle, 4 of them per lane reach the HBM-bound regime.
+template <typename T, int MAXV, int R>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, long ldx,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y, long ldy,
@@ -34,57 +36,86 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
                                                             int act_gelu) {
   const int nvec = Cp >> 3;
   const int gl = threadIdx.x & (G - 1);
-  const long m = (long)blockIdx.x * (256 / G) + threadIdx.x / G;
-  const bool row_ok = m < M;
-  float v[MAXV][8];
-  float s = 0.f;
+  const int rpi = 256 / G;
+  const long mb = ((long)blockIdx.x * R) * rpi + threadIdx.x / G;
+  float v[R][MAXV][8];
+  float s[R];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int vi = gl + i * G;
+  for (int r = 0; r < R; ++r) {
+    const long m = mb + (long)r * rpi;
+    s[r] = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) v[i][c] = 0.f;
-    if (row_ok && vi < nvec) load8(x + m * ldx + vi * 8, v[i]);
+    for (int i = 0; i < MAXV; ++i) {
+      const int vi = gl + i * G;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) s += (vi * 8 + c < C) ? v[i][c] : 0.f;
-  }
-  s = group_sum(s, G);
-  const float mean = s / (float)C;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int vi = gl + i * G;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const float d = v[i][c] - mean;
-      q += (vi < nvec && vi * 8 + c < C) ? d * d : 0.f;
+      for (int c = 0; c < 8; ++c) v[r][i][c] = 0.f;
+      if (m < M && vi < nvec) load8(x + m * ldx + vi * 8, v[r][i]);
     }
   }
-  q = group_sum(q, G);
-  const float rstd = rsqrtf(q / (float)C + 1e-6f);
-  if (!row_ok) return;
-  if (gl == 0 && stats) {
-    stats[2 * m] = mean;
-    stats[2 * m + 1] = rstd;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int vi = gl + i * G;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) s[r] += (vi * 8 + c < C) ? v[r][i][c] : 0.f;
+    }
   }
+#pragma unroll
+  for (int r = 0; r < R; ++r) s[r] = group_sum(s[r], G) / (float)C;  // mean
+  float q[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    q[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int vi = gl + i * G;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float d = v[r][i][c] - s[r];
+        q[r] += (vi < nvec && vi * 8 + c < C) ? d * d : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) q[r] = rsqrtf(group_sum(q[r], G) / (float)C + 1e-6f);  // rstd
+  // gamma / beta are zero padded to Cp, so pad channels come out as act(0) = 0 without a branch
+  float gv[MAXV][8], bv[MAXV][8];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int vi = gl + i * G;
-    if (vi >= nvec) continue;
-    // gamma / beta are zero padded to Cp, so pad channels come out as act(0) = 0 without a branch
-    float gv[8], bv[8], o[8];
-    load8(gamma + vi * 8, gv);
-    load8(beta + vi * 8, bv);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float u = (v[i][c] - mean) * rstd * gv[c] + bv[c];
-      if (act_gelu) u = gelu_f(u);
-      o[c] = u;
+    for (int c = 0; c < 8; ++c) { gv[i][c] = 0.f; bv[i][c] = 0.f; }
+    if (vi < nvec) {
+      load8(gamma + vi * 8, gv[i]);
+      load8(beta + vi * 8, bv[i]);
     }
-    store8(y + m * ldy + vi * 8, o);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const long m = mb + (long)r * rpi;
+    if (m >= M) continue;
+    if (gl == 0 && stats) {
+      stats[2 * m] = s[r];
+      stats[2 * m + 1] = q[r];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int vi = gl + i * G;
+      if (vi >= nvec) continue;
+      float o[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float u = (v[r][i][c] - s[r]) * q[r] * gv[i][c] + bv[i][c];
+        if (act_gelu) u = gelu_f(u);
+        o[c] = u;
+      }
+      store8(y + m * ldy + vi * 8, o);
+    }
   }
 }
 
-template <typename T, int MAXV>
+template <typename T, int MAXV, int R>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, long ldx,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
@@ -95,7 +126,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   const int nvec = Cp >> 3;
   const int gl = threadIdx.x & (G - 1);
   const int rl = threadIdx.x / G;
-  const int rpi = 256 / G;  // rows per iteration
+  const int rpi = 256 / G;  // rows per sub-iteration
   const long mbeg = (long)blockIdx.x * rows_per_block;
   const long mend = mbeg + rows_per_block < M ? mbeg + rows_per_block : M;
   float dg[MAXV][8], db[MAXV][8], gm[MAXV][8], bt[MAXV][8];
@@ -106,46 +137,68 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     for (int c = 0; c < 8; ++c) {
       dg[i][c] = 0.f;
       db[i][c] = 0.f;
-      const int cc = vi * 8 + c;
-      gm[i][c] = (vi < nvec) ? gamma[cc] : 0.f;  // zero padded to Cp by the caller
-      bt[i][c] = (vi < nvec) ? beta[cc] : 0.f;
+      gm[i][c] = 0.f;
+      bt[i][c] = 0.f;
+    }
+    if (vi < nvec) {  // zero padded to Cp by the caller
+      load8(gamma + vi * 8, gm[i]);
+      load8(beta + vi * 8, bt[i]);
     }
   }
-  for (long m0 = mbeg; m0 < mend; m0 += rpi) {
-    const long m = m0 + rl;
-    const bool ok = m < mend;
-    const float mean = ok ? stats[2 * m] : 0.f;
-    const float rstd = ok ? stats[2 * m + 1] : 0.f;
-    float xh[MAXV][8], g[MAXV][8];
-    float s1 = 0.f, s2 = 0.f;
+  for (long m0 = mbeg; m0 < mend; m0 += (long)R * rpi) {
+    float xh[R][MAXV][8], g[R][MAXV][8];  // first hold the raw x / dy, then x-hat / effective gradient
+    float mean[R], rstd[R];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int vi = gl + i * G;
-      float xv[8], dv[8];
+    for (int r = 0; r < R; ++r) {
+      const long m = m0 + (long)r * rpi + rl;
+      const bool ok = m < mend;
+      mean[r] = ok ? stats[2 * m] : 0.f;
+      rstd[r] = ok ? stats[2 * m + 1] : 0.f;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) { xv[c] = 0.f; dv[c] = 0.f; }
-      if (ok && vi < nvec) {
-        load8(x + m * ldx + vi * 8, xv);
-        load8(dy + m * lddy + vi * 8, dv);
-      }
+      for (int i = 0; i < MAXV; ++i) {
+        const int vi = gl + i * G;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const bool cok = ok && vi < nvec && (vi * 8 + c < C);
-        const float h = cok ? (xv[c] - mean) * rstd : 0.f;
-        float gg = cok ? dv[c] : 0.f;
-        if (act_gelu) gg *= dgelu_f(h * gm[i][c] + bt[i][c]);
-        xh[i][c] = h;
-        g[i][c] = gg;
-        dg[i][c] += gg * h;
-        db[i][c] += gg;
-        const float dxh = gg * gm[i][c];
-        s1 += dxh;
-        s2 += dxh * h;
+        for (int c = 0; c < 8; ++c) { xh[r][i][c] = 0.f; g[r][i][c] = 0.f; }
+        if (ok && vi < nvec) {
+          load8(x + m * ldx + vi * 8, xh[r][i]);
+          load8(dy + m * lddy + vi * 8, g[r][i]);
+        }
       }
     }
-    s1 = group_sum(s1, G) / (float)C;
-    s2 = group_sum(s2, G) / (float)C;
-    if (ok) {
+    float s1[R], s2[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool ok = m0 + (long)r * rpi + rl < mend;
+      s1[r] = 0.f;
+      s2[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int vi = gl + i * G;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const bool cok = ok && vi < nvec && (vi * 8 + c < C);
+          const float h = cok ? (xh[r][i][c] - mean[r]) * rstd[r] : 0.f;
+          float gg = cok ? g[r][i][c] : 0.f;
+          if (act_gelu) gg *= dgelu_f(h * gm[i][c] + bt[i][c]);
+          xh[r][i][c] = h;
+          g[r][i][c] = gg;
+          dg[i][c] += gg * h;
+          db[i][c] += gg;
+          const float dxh = gg * gm[i][c];
+          s1[r] += dxh;
+          s2[r] += dxh * h;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      s1[r] = group_sum(s1[r], G) / (float)C;
+      s2[r] = group_sum(s2[r], G) / (float)C;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const long m = m0 + (long)r * rpi + rl;
+      if (m >= mend) continue;
 #pragma unroll
       for (int i = 0; i < MAXV; ++i) {
         const int vi = gl + i * G;
@@ -154,7 +207,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const bool cok = vi * 8 + c < C;
-          o[c] = cok ? rstd * (g[i][c] * gm[i][c] - s1 - xh[i][c] * s2) : 0.f;
+          o[c] = cok ? rstd[r] * (g[r][i][c] * gm[i][c] - s1[r] - xh[r][i][c] * s2[r]) : 0.f;
         }
         store8(dx + m * lddx + vi * 8, o);
       }
@@ -238,7 +291,7 @@ __global__ __launch_bounds__(256) void scale_res_bwd_kernel(const T* __restrict_
 }
 
 static inline long rows_per_block_for(long M, long quantum) {
-  long r = vkas_cdiv(M > 0 ? M : 1, 1024);
+  long r = vkas_cdiv(M > 0 ? M : 1, 2048);
   if (r < 256) r = 256;
   return vkas_cdiv(r, quantum) * quantum;
 }
@@ -256,14 +309,13 @@ extern "C" int vkas_layernorm_fwd(const void* x, long ldx, const float* gamma, c
   const long rows = 256 / G;
   const int vpl = (int)vkas_cdiv(Cp >> 3, G);
   VKAS_DISPATCH_DTYPE(dtype, "vkas_layernorm_fwd", {
-    const unsigned grid = (unsigned)vkas_cdiv(M, rows);
     hipStream_t st = vkas_stream(stream);
     if (vpl == 1)
-      layernorm_fwd_kernel<T, 1><<<grid, 256, 0, st>>>((const T*)x, ldx, gamma, beta, (T*)y, ldy, stats, M, C, Cp, G, act_gelu);
+      layernorm_fwd_kernel<T, 1, 4><<<(unsigned)vkas_cdiv(M, rows * 4), 256, 0, st>>>((const T*)x, ldx, gamma, beta, (T*)y, ldy, stats, M, C, Cp, G, act_gelu);
     else if (vpl == 2)
-      layernorm_fwd_kernel<T, 2><<<grid, 256, 0, st>>>((const T*)x, ldx, gamma, beta, (T*)y, ldy, stats, M, C, Cp, G, act_gelu);
+      layernorm_fwd_kernel<T, 2, 2><<<(unsigned)vkas_cdiv(M, rows * 2), 256, 0, st>>>((const T*)x, ldx, gamma, beta, (T*)y, ldy, stats, M, C, Cp, G, act_gelu);
     else
-      layernorm_fwd_kernel<T, 4><<<grid, 256, 0, st>>>((const T*)x, ldx, gamma, beta, (T*)y, ldy, stats, M, C, Cp, G, act_gelu);
+      layernorm_fwd_kernel<T, 4, 1><<<(unsigned)vkas_cdiv(M, rows), 256, 0, st>>>((const T*)x, ldx, gamma, beta, (T*)y, ldy, stats, M, C, Cp, G, act_gelu);
   })
   VKAS_LAUNCH_CHECK("layernorm_fwd");
   return VKAS_OK;
@@ -271,7 +323,7 @@ extern "C" int vkas_layernorm_fwd(const void* x, long ldx, const float* gamma, c
 
 extern "C" size_t vkas_layernorm_bwd_ws_bytes(long M, int Cp) {
   const int G = pick_group(Cp >> 3);
-  const long rpb = rows_per_block_for(M, 256 / G);
+  const long rpb = rows_per_block_for(M, 2 * (256 / G));
   return (size_t)vkas_cdiv(M > 0 ? M : 1, rpb) * 2 * (size_t)Cp * sizeof(float);
 }
 
@@ -292,18 +344,18 @@ extern "C" int vkas_layernorm_bwd(const void* x, long ldx, const float* gamma, c
     return VKAS_OK;
   }
   const int G = pick_group(Cp >> 3);
-  const long rpb = rows_per_block_for(M, 256 / G);
+  const long rpb = rows_per_block_for(M, 2 * (256 / G));
   const long P = vkas_cdiv(M, rpb);
   const int vpl = (int)vkas_cdiv(Cp >> 3, G);
   VKAS_DISPATCH_DTYPE(dtype, "vkas_layernorm_bwd", {
     if (vpl == 1)
-      layernorm_bwd_kernel<T, 1><<<(unsigned)P, 256, 0, st>>>((const T*)x, ldx, gamma, beta, stats, (const T*)dy, lddy,
+      layernorm_bwd_kernel<T, 1, 2><<<(unsigned)P, 256, 0, st>>>((const T*)x, ldx, gamma, beta, stats, (const T*)dy, lddy,
                                                               (T*)dx, lddx, ws, M, C, Cp, G, act_gelu, rpb);
     else if (vpl == 2)
-      layernorm_bwd_kernel<T, 2><<<(unsigned)P, 256, 0, st>>>((const T*)x, ldx, gamma, beta, stats, (const T*)dy, lddy,
+      layernorm_bwd_kernel<T, 2, 1><<<(unsigned)P, 256, 0, st>>>((const T*)x, ldx, gamma, beta, stats, (const T*)dy, lddy,
                                                               (T*)dx, lddx, ws, M, C, Cp, G, act_gelu, rpb);
     else
-      layernorm_bwd_kernel<T, 4><<<(unsigned)P, 256, 0, st>>>((const T*)x, ldx, gamma, beta, stats, (const T*)dy, lddy,
+      layernorm_bwd_kernel<T, 4, 1><<<(unsigned)P, 256, 0, st>>>((const T*)x, ldx, gamma, beta, stats, (const T*)dy, lddy,
                                                               (T*)dx, lddx, ws, M, C, Cp, G, act_gelu, rpb);
   })
   VKAS_LAUNCH_CHECK("layernorm_bwd");

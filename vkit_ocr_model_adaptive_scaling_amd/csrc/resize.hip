@@ -34,107 +34,146 @@ __device__ __forceinline__ float axis_weight(int dst, float scale, int n_in, int
   return nearest_src(dst, n_in, n_out) == src_i ? 1.f : 0.f;
 }
 
+// grid.x = B*Hout rows, grid.y = chunks of 256 (pixel, vector) pairs of one row: no 64-bit index arithmetic.
 template <typename T>
 __global__ __launch_bounds__(256) void resize_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
-                                                         int B, int Hin, int Win, int Hout, int Wout, int nvec, int mode,
+                                                         int Hin, int Win, int Hout, int Wout, int nvec, int mode,
                                                          int accumulate) {
-  const long total = (long)B * Hout * Wout * nvec;
+  const int idx = blockIdx.y * 256 + threadIdx.x;
+  const int ox = idx / nvec;
+  const int v = idx - ox * nvec;
+  if (ox >= Wout) return;
+  const int b = blockIdx.x / Hout;
+  const int oy = blockIdx.x - b * Hout;
   const float sy = (float)Hin / (float)Hout, sx = (float)Win / (float)Wout;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int v = (int)(i % nvec);
-    long p = i / nvec;
-    const int ox = (int)(p % Wout);
-    p /= Wout;
-    const int oy = (int)(p % Hout);
-    const int b = (int)(p / Hout);
-    float o[8];
-    const T* xb = x + (long)b * Hin * Win * ldx + v * 8;
-    if (mode == 0) {
-      int y0, y1, x0, x1;
-      float wy, wx;
-      bilinear_src(oy, sy, Hin, y0, y1, wy);
-      bilinear_src(ox, sx, Win, x0, x1, wx);
-      float a[8], bq[8], c[8], d[8];
-      load8(xb + ((long)y0 * Win + x0) * ldx, a);
-      load8(xb + ((long)y0 * Win + x1) * ldx, bq);
-      load8(xb + ((long)y1 * Win + x0) * ldx, c);
-      load8(xb + ((long)y1 * Win + x1) * ldx, d);
+  float o[8];
+  const T* xb = x + (long)b * Hin * Win * ldx + v * 8;
+  if (mode == 0) {
+    int y0, y1, x0, x1;
+    float wy, wx;
+    bilinear_src(oy, sy, Hin, y0, y1, wy);
+    bilinear_src(ox, sx, Win, x0, x1, wx);
+    float a[8], bq[8], c[8], d[8];
+    load8(xb + ((long)y0 * Win + x0) * ldx, a);
+    load8(xb + ((long)y0 * Win + x1) * ldx, bq);
+    load8(xb + ((long)y1 * Win + x0) * ldx, c);
+    load8(xb + ((long)y1 * Win + x1) * ldx, d);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float top = a[k] * (1.f - wx) + bq[k] * wx;
-        const float bot = c[k] * (1.f - wx) + d[k] * wx;
-        o[k] = top * (1.f - wy) + bot * wy;
-      }
-    } else {
-      const int iy = nearest_src(oy, Hin, Hout), ix = nearest_src(ox, Win, Wout);
-      load8(xb + ((long)iy * Win + ix) * ldx, o);
+    for (int k = 0; k < 8; ++k) {
+      const float top = a[k] * (1.f - wx) + bq[k] * wx;
+      const float bot = c[k] * (1.f - wx) + d[k] * wx;
+      o[k] = top * (1.f - wy) + bot * wy;
     }
-    T* dst = y + (((long)b * Hout + oy) * Wout + ox) * ldy + v * 8;
-    if (accumulate) {
-      float t[8];
-      load8(dst, t);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] += t[k];
-    }
-    store8(dst, o);
+  } else {
+    const int iy = nearest_src(oy, Hin, Hout), ix = nearest_src(ox, Win, Wout);
+    load8(xb + ((long)iy * Win + ix) * ldx, o);
   }
+  T* dst = y + (((long)b * Hout + oy) * Wout + ox) * ldy + v * 8;
+  if (accumulate) {
+    float t[8];
+    load8(dst, t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] += t[k];
+  }
+  store8(dst, o);
+}
+
+// destination range [lo, hi] along one axis that reads source index i (tight; empty if lo > hi)
+__device__ __forceinline__ void dst_range(int i, int n_in, int n_out, float scale, int mode, int& lo, int& hi) {
+  const float r = (float)n_out / (float)n_in;
+  if (mode == 0) {
+    lo = (int)floorf(((float)i - 1.f) * r) - 2;
+    hi = (int)ceilf(((float)i + 1.5f) * r) + 2;
+  } else {
+    lo = (int)floorf((float)i * r) - 2;
+    hi = (int)ceilf(((float)i + 1.f) * r) + 2;
+  }
+  if (i == n_in - 1) hi = n_out - 1;  // the last source index also collects every clamped destination
+  if (lo < 0) lo = 0;
+  if (hi > n_out - 1) hi = n_out - 1;
+  while (lo <= hi && axis_weight(lo, scale, n_in, n_out, i, mode) == 0.f) ++lo;
+  while (hi >= lo && axis_weight(hi, scale, n_in, n_out, i, mode) == 0.f) --hi;
 }
 
 // dx[b,iy,ix] (+)= sum over destination pixels (oy,ox) of weight(oy->iy) * weight(ox->ix) * dy[b,oy,ox]
+// grid.x = B*Hin rows, grid.y = chunks of 256 (pixel, vector) pairs of one source row.
 template <typename T>
 __global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ dy, long lddy, T* __restrict__ dx,
-                                                         long lddx, int B, int Hin, int Win, int Hout, int Wout,
-                                                         int nvec, int mode, int accumulate) {
-  const long total = (long)B * Hin * Win * nvec;
+                                                         long lddx, int Hin, int Win, int Hout, int Wout, int nvec,
+                                                         int mode, int accumulate) {
+  const int idx = blockIdx.y * 256 + threadIdx.x;
+  const int ix = idx / nvec;
+  const int v = idx - ix * nvec;
+  if (ix >= Win) return;
+  const int b = blockIdx.x / Hin;
+  const int iy = blockIdx.x - b * Hin;
   const float sy = (float)Hin / (float)Hout, sx = (float)Win / (float)Wout;
-  const float ry = (float)Hout / (float)Hin, rx = (float)Wout / (float)Win;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int v = (int)(i % nvec);
-    long p = i / nvec;
-    const int ix = (int)(p % Win);
-    p /= Win;
-    const int iy = (int)(p % Hin);
-    const int b = (int)(p / Hin);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const T* db = dy + (long)b * Hout * Wout * lddy + v * 8;
-    // candidate destination ranges (conservative; every candidate is re-checked with the forward index function)
-    int oy_lo, oy_hi, ox_lo, ox_hi;
-    if (mode == 0) {
-      oy_lo = (int)floorf(((float)iy - 1.f) * ry) - 2;
-      oy_hi = (int)ceilf(((float)iy + 1.5f) * ry) + 2;
-      ox_lo = (int)floorf(((float)ix - 1.f) * rx) - 2;
-      ox_hi = (int)ceilf(((float)ix + 1.5f) * rx) + 2;
-    } else {
-      oy_lo = (int)floorf((float)iy * ry) - 2;
-      oy_hi = (int)ceilf(((float)iy + 1.f) * ry) + 2;
-      ox_lo = (int)floorf((float)ix * rx) - 2;
-      ox_hi = (int)ceilf(((float)ix + 1.f) * rx) + 2;
-    }
-    // the last source row/column also collects every clamped destination
-    if (iy == Hin - 1) oy_hi = Hout - 1;
-    if (ix == Win - 1) ox_hi = Wout - 1;
-    if (oy_lo < 0) oy_lo = 0;
-    if (ox_lo < 0) ox_lo = 0;
-    if (oy_hi > Hout - 1) oy_hi = Hout - 1;
-    if (ox_hi > Wout - 1) ox_hi = Wout - 1;
-    // tighten both ranges to the destinations that really reference this source pixel
-    while (oy_lo <= oy_hi && axis_weight(oy_lo, sy, Hin, Hout, iy, mode) == 0.f) ++oy_lo;
-    while (oy_hi >= oy_lo && axis_weight(oy_hi, sy, Hin, Hout, iy, mode) == 0.f) --oy_hi;
-    while (ox_lo <= ox_hi && axis_weight(ox_lo, sx, Win, Wout, ix, mode) == 0.f) ++ox_lo;
-    while (ox_hi >= ox_lo && axis_weight(ox_hi, sx, Win, Wout, ix, mode) == 0.f) --ox_hi;
-    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-      const float wyv = axis_weight(oy, sy, Hin, Hout, iy, mode);
-      if (wyv == 0.f) continue;
-      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        const float wxv = axis_weight(ox, sx, Win, Wout, ix, mode);
-        if (wxv == 0.f) continue;
-        float t[8];
-        load8(db + ((long)oy * Wout + ox) * lddy, t);
-        const float wgt = wyv * wxv;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const T* db = dy + (long)b * Hout * Wout * lddy + v * 8;
+  int oy_lo, oy_hi, ox_lo, ox_hi;
+  dst_range(iy, Hin, Hout, sy, mode, oy_lo, oy_hi);
+  dst_range(ix, Win, Wout, sx, mode, ox_lo, ox_hi);
+  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+    const float wyv = axis_weight(oy, sy, Hin, Hout, iy, mode);
+    if (wyv == 0.f) continue;
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+      const float wxv = axis_weight(ox, sx, Win, Wout, ix, mode);
+      if (wxv == 0.f) continue;
+      float t[8];
+      load8(db + ((long)oy * Wout + ox) * lddy, t);
+      const float wgt = wyv * wxv;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = fmaf(wgt, t[k], acc[k]);
-      }
+      for (int k = 0; k < 8; ++k) acc[k] = fmaf(wgt, t[k], acc[k]);
     }
+  }
+  T* dst = dx + (((long)b * Hin + iy) * Win + ix) * lddx + v * 8;
+  if (accumulate) {
+    float t[8];
+    load8(dst, t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += t[k];
+  }
+  store8(dst, acc);
+}
+
+// Tiny sources (PPM maps of 1..6 pixels upsampled to 32x32): one workgroup per source pixel, the destination
+// footprint is spread over the threads and reduced through LDS.  nvec <= 256.
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bwd_small_kernel(const T* __restrict__ dy, long lddy, T* __restrict__ dx,
+                                                               long lddx, int Hin, int Win, int Hout, int Wout, int nvec,
+                                                               int mode, int accumulate) {
+  __shared__ float red[256 * 8];
+  const int ix = blockIdx.x % Win;
+  const int iy = (blockIdx.x / Win) % Hin;
+  const int b = blockIdx.x / (Win * Hin);
+  const int lanes_p = 256 / nvec;
+  const int v = threadIdx.x % nvec;
+  const int pl = threadIdx.x / nvec;
+  const float sy = (float)Hin / (float)Hout, sx = (float)Win / (float)Wout;
+  int oy_lo, oy_hi, ox_lo, ox_hi;
+  dst_range(iy, Hin, Hout, sy, mode, oy_lo, oy_hi);
+  dst_range(ix, Win, Wout, sx, mode, ox_lo, ox_hi);
+  const int nx = ox_hi - ox_lo + 1, ny = oy_hi - oy_lo + 1;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (pl < lanes_p && nx > 0 && ny > 0) {
+    const T* db = dy + (long)b * Hout * Wout * lddy + v * 8;
+    for (int p = pl; p < nx * ny; p += lanes_p) {
+      const int oy = oy_lo + p / nx, ox = ox_lo + p % nx;
+      const float wgt = axis_weight(oy, sy, Hin, Hout, iy, mode) * axis_weight(ox, sx, Win, Wout, ix, mode);
+      if (wgt == 0.f) continue;
+      float t[8];
+      load8(db + ((long)oy * Wout + ox) * lddy, t);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = fmaf(wgt, t[k], acc[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = acc[k];
+  __syncthreads();
+  if (pl == 0) {
+    for (int r = 1; r < lanes_p; ++r)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += red[(r * nvec + v) * 8 + k];
     T* dst = dx + (((long)b * Hin + iy) * Win + ix) * lddx + v * 8;
     if (accumulate) {
       float t[8];
@@ -152,29 +191,39 @@ __device__ __forceinline__ void pool_bin(int i, int n, int s, int& lo, int& hi) 
   hi = ((i + 1) * n + s - 1) / s;
 }
 
+// one workgroup per (b, bin): the bin's pixels are spread over the threads and reduced through LDS.  nvec <= 256.
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
                                                           int B, int H, int W, int s, int nvec) {
-  const long total = (long)B * s * s * nvec;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int v = (int)(i % nvec);
-    long p = i / nvec;
-    const int bj = (int)(p % s);
-    p /= s;
-    const int bi = (int)(p % s);
-    const int b = (int)(p / s);
-    int y0, y1, x0, x1;
-    pool_bin(bi, H, s, y0, y1);
-    pool_bin(bj, W, s, x0, x1);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int yy = y0; yy < y1; ++yy)
-      for (int xx = x0; xx < x1; ++xx) {
-        float t[8];
-        load8(x + (((long)b * H + yy) * W + xx) * ldx + v * 8, t);
+  __shared__ float red[256 * 8];
+  const int bj = blockIdx.x % s;
+  const int bi = (blockIdx.x / s) % s;
+  const int b = blockIdx.x / (s * s);
+  const int lanes_p = 256 / nvec;
+  const int v = threadIdx.x % nvec;
+  const int pl = threadIdx.x / nvec;
+  int y0, y1, x0, x1;
+  pool_bin(bi, H, s, y0, y1);
+  pool_bin(bj, W, s, x0, x1);
+  const int nx = x1 - x0, np = (y1 - y0) * nx;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (pl < lanes_p) {
+    for (int p = pl; p < np; p += lanes_p) {
+      const int yy = y0 + p / nx, xx = x0 + p % nx;
+      float t[8];
+      load8(x + (((long)b * H + yy) * W + xx) * ldx + v * 8, t);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] += t[k];
-      }
-    const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+      for (int k = 0; k < 8; ++k) acc[k] += t[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = acc[k];
+  __syncthreads();
+  if (pl == 0) {
+    for (int r = 1; r < lanes_p; ++r)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += red[(r * nvec + v) * 8 + k];
+    const float inv = 1.f / (float)np;
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] *= inv;
     store8(y + (((long)b * s + bi) * s + bj) * ldy + v * 8, acc);
@@ -243,11 +292,12 @@ extern "C" int vkas_resize_fwd(const void* x, long ldx, void* y, long ldy, int B
   int rc = rs_check("vkas_resize_fwd", x, ldx, y, ldy, B, Hin, Win, Hout, Wout, Cp);
   if (rc) return rc;
   VKAS_CHECK(mode == 0 || mode == 1, "vkas_resize_fwd: bad mode %d", mode);
-  const long total = (long)B * Hout * Wout * (Cp / 8);
-  if (total == 0) return VKAS_OK;
+  if (B == 0) return VKAS_OK;
+  VKAS_CHECK((long)Wout * (Cp / 8) < (1L << 30) && vkas_cdiv((long)Wout * (Cp / 8), 256) <= 65535, "vkas_resize_fwd: row too wide");
+  dim3 grid((unsigned)((long)B * Hout), (unsigned)vkas_cdiv((long)Wout * (Cp / 8), 256));
   VKAS_DISPATCH_DTYPE(dtype, "vkas_resize_fwd", {
-    resize_fwd_kernel<T><<<grid_for(total), 256, 0, vkas_stream(stream)>>>((const T*)x, ldx, (T*)y, ldy, B, Hin, Win,
-                                                                          Hout, Wout, Cp / 8, mode, accumulate);
+    resize_fwd_kernel<T><<<grid, 256, 0, vkas_stream(stream)>>>((const T*)x, ldx, (T*)y, ldy, Hin, Win, Hout, Wout, Cp / 8,
+                                                               mode, accumulate);
   })
   VKAS_LAUNCH_CHECK("resize_fwd");
   return VKAS_OK;
@@ -258,11 +308,18 @@ extern "C" int vkas_resize_bwd(const void* dy, long lddy, void* dx, long lddx, i
   int rc = rs_check("vkas_resize_bwd", dy, lddy, dx, lddx, B, Hin, Win, Hout, Wout, Cp);
   if (rc) return rc;
   VKAS_CHECK(mode == 0 || mode == 1, "vkas_resize_bwd: bad mode %d", mode);
-  const long total = (long)B * Hin * Win * (Cp / 8);
-  if (total == 0) return VKAS_OK;
+  if (B == 0) return VKAS_OK;
+  VKAS_CHECK((long)Win * (Cp / 8) < (1L << 30) && vkas_cdiv((long)Win * (Cp / 8), 256) <= 65535, "vkas_resize_bwd: row too wide");
+  const bool small = (long)Hin * Win <= 64 && (long)Hout * Wout >= 16L * Hin * Win && Cp / 8 <= 256;
   VKAS_DISPATCH_DTYPE(dtype, "vkas_resize_bwd", {
-    resize_bwd_kernel<T><<<grid_for(total), 256, 0, vkas_stream(stream)>>>((const T*)dy, lddy, (T*)dx, lddx, B, Hin, Win,
-                                                                          Hout, Wout, Cp / 8, mode, accumulate);
+    if (small) {
+      resize_bwd_small_kernel<T><<<(unsigned)((long)B * Hin * Win), 256, 0, vkas_stream(stream)>>>(
+          (const T*)dy, lddy, (T*)dx, lddx, Hin, Win, Hout, Wout, Cp / 8, mode, accumulate);
+    } else {
+      dim3 grid((unsigned)((long)B * Hin), (unsigned)vkas_cdiv((long)Win * (Cp / 8), 256));
+      resize_bwd_kernel<T><<<grid, 256, 0, vkas_stream(stream)>>>((const T*)dy, lddy, (T*)dx, lddx, Hin, Win, Hout, Wout,
+                                                                 Cp / 8, mode, accumulate);
+    }
   })
   VKAS_LAUNCH_CHECK("resize_bwd");
   return VKAS_OK;
@@ -273,11 +330,11 @@ extern "C" int vkas_adaptive_avgpool_fwd(const void* x, long ldx, void* y, long 
   VKAS_CHECK(s > 0, "vkas_adaptive_avgpool_fwd: bad s");
   int rc = rs_check("vkas_adaptive_avgpool_fwd", x, ldx, y, ldy, B, H, W, s, s, Cp);
   if (rc) return rc;
-  const long total = (long)B * s * s * (Cp / 8);
-  if (total == 0) return VKAS_OK;
+  if (B == 0) return VKAS_OK;
+  VKAS_CHECK(Cp / 8 <= 256, "vkas_adaptive_avgpool_fwd: at most 2048 channels");
   VKAS_DISPATCH_DTYPE(dtype, "vkas_adaptive_avgpool_fwd", {
-    avgpool_fwd_kernel<T><<<grid_for(total), 256, 0, vkas_stream(stream)>>>((const T*)x, ldx, (T*)y, ldy, B, H, W, s,
-                                                                           Cp / 8);
+    avgpool_fwd_kernel<T><<<(unsigned)((long)B * s * s), 256, 0, vkas_stream(stream)>>>((const T*)x, ldx, (T*)y, ldy, B, H,
+                                                                                       W, s, Cp / 8);
   })
   VKAS_LAUNCH_CHECK("adaptive_avgpool_fwd");
   return VKAS_OK;
