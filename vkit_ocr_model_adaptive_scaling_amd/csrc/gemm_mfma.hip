@@ -39,8 +39,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const long m0 = (long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  // Tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private L2), so give every XCD a
+  // contiguous run of tiles, N tiles fastest: the N tiles of one pixel block and its vertical neighbours (the 3x3
+  // halo rows) then hit the same L2 instead of re-reading A from HBM.  Pure speed choice, any placement is correct.
+  const unsigned ntile_n = (unsigned)((Np + BN - 1) / BN);
+  const unsigned total = gridDim.x;
+  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const unsigned q8 = total >> 3, r8 = total & 7u;
+  const unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  const long m0 = (long)(tile / ntile_n) * BM;
+  const int n0 = (int)(tile % ntile_n) * BN;
 
   // staging role: chunk column cc (8 elements), rows sr + RSTEP*i
   const int cc = tid & 7;
@@ -118,13 +126,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
   const int nk = (K + BK - 1) / BK;
   load_tile();
   store_tile(0);
+  if (nk > 1) load_tile();  // registers now hold tile 1
   __syncthreads();
 
   const int frow = lane & 15;
   const int fchunk = lane >> 4;
+  // Per K tile: first MFMA half | registers (tile kt+1, loaded one and a half iterations ago) -> LDS, reissue the
+  // global loads for tile kt+2 | second MFMA half | barrier.  The LDS write latency and the global-load latency
+  // both sit behind MFMA work instead of in front of the barrier.
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile();
     const bf16_t* As = lds + buf * (BM + BN) * BK;
     const bf16_t* Bs = As + BM * BK;
 #pragma unroll
@@ -136,13 +147,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         fb[j] = *reinterpret_cast<const bf16x8*>(Bs + swz_off(wn * TN * 16 + j * 16 + frow, s * 4 + fchunk));
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if (s == 0 && kt + 1 < nk) {
+        store_tile(buf ^ 1);
+        if (kt + 2 < nk) load_tile();
+      }
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
     __syncthreads();
   }
 
@@ -316,11 +332,11 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
   if (nit > 0) {
     load_tile();
     store_tile(0);
+    if (nit > 1) load_tile();  // registers now hold chunk 1
   }
   __syncthreads();
   for (int it = 0; it < nit; ++it) {
     const int buf = it & 1;
-    if (it + 1 < nit) load_tile();
     const bf16_t* Ds = lds + buf * TILE;
     const bf16_t* Xs = Ds + TN_ROWS * LDD;
 #pragma unroll
@@ -330,19 +346,24 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
       for (int i = 0; i < TNn; ++i) fd[i] = tr_frag<LDD>(Ds, s * 32, wn * TNn * 16 + i * 16, lane);
 #pragma unroll
       for (int j = 0; j < TK; ++j) fx[j] = tr_frag<LDX>(Xs, s * 32, wk * TK * 16 + j * 16, lane);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < TNn; ++i)
 #pragma unroll
         for (int j = 0; j < TK; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[i], fx[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
       if (do_bias) {
 #pragma unroll
         for (int i = 0; i < TNn; ++i)
 #pragma unroll
           for (int q = 0; q < 8; ++q) bsum[i] += (float)fd[i][q];
       }
+      if (s == 0 && it + 1 < nit) {  // stage chunk it+1 and reissue the loads of chunk it+2 behind the MFMAs
+        store_tile(buf ^ 1);
+        if (it + 2 < nit) load_tile();
+      }
     }
-    if (it + 1 < nit) store_tile(buf ^ 1);
     __syncthreads();
   }
   // D[row = n_local][col = k_local]: lane holds col = lane&15, rows (lane>>4)*4 + r
@@ -377,7 +398,7 @@ template <int WM, int WN, int TM, int TN>
 static void launch_nt(const void* x, const vkas_conv_geom* g, const void* Bw, int Np, long M, int K,
                       const vkas_epilogue* e, hipStream_t st) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  dim3 grid((unsigned)vkas_cdiv(M, BM), (unsigned)vkas_cdiv(Np, BN));
+  dim3 grid((unsigned)(vkas_cdiv(M, BM) * vkas_cdiv(Np, BN)));
   gemm_nt_mfma_kernel<WM, WN, TM, TN><<<grid, WM * WN * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)Bw, Np, M, K, *e);
 }
 
