@@ -118,10 +118,14 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # VKAS_DIST_BACKEND=gloo lets the N>1 control flow (bucket arming, hooks, flush) be rehearsed on a one-GPU box with
+    # every rank on device 0; the real runs use nccl (= RCCL over xGMI), one rank per GPU.
+    backend = os.environ.get('VKAS_DIST_BACKEND', 'nccl')
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     torch.manual_seed(1234)  # identical initial weights on every rank
@@ -137,6 +141,7 @@ def main():
     torch.manual_seed(99 + rank)  # stochastic-depth masks differ per rank
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

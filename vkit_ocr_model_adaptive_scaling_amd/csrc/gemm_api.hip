@@ -131,28 +131,35 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 }
 }  // namespace
 
-// out[c] (+)= sum_p partial[p][c]; 32 columns x 8 row lanes per block, fixed summation order => deterministic.
+// out[c] (+)= sum_p partial[p][c]; 16 columns x 16 row lanes per block, fixed summation order => deterministic.
 __global__ __launch_bounds__(256) void vkas_colreduce_finalize_kernel(const float* __restrict__ partial, long P, int n,
                                                                       int ldp, float* __restrict__ out,
                                                                       int accumulate) {
-  __shared__ float red[8][33];
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  float s = 0.f;
-  if (c < n)
-    for (long p = rl; p < P; p += 8) s += partial[p * ldp + c];
-  red[rl][cl] = s;
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < n) {
+    long p = rl;
+    for (; p + 16 < P; p += 32) {
+      s0 += partial[p * ldp + c];
+      s1 += partial[(p + 16) * ldp + c];
+    }
+    if (p < P) s0 += partial[p * ldp + c];
+  }
+  red[rl][cl] = s0 + s1;
   __syncthreads();
   if (rl == 0 && c < n) {
+    float s = 0.f;
 #pragma unroll
-    for (int r = 1; r < 8; ++r) s += red[r][cl];
+    for (int r = 0; r < 16; ++r) s += red[r][cl];
     out[c] = accumulate ? out[c] + s : s;
   }
 }
 
 int vkas_colreduce_finalize(const float* partial, long P, int n, int ldp, float* out, int accumulate,
                             hipStream_t st) {
-  vkas_colreduce_finalize_kernel<<<(unsigned)vkas_cdiv(n, 32), 256, 0, st>>>(partial, P, n, ldp, out, accumulate);
+  vkas_colreduce_finalize_kernel<<<(unsigned)vkas_cdiv(n, 16), 256, 0, st>>>(partial, P, n, ldp, out, accumulate);
   VKAS_LAUNCH_CHECK("colreduce_finalize");
   return VKAS_OK;
 }

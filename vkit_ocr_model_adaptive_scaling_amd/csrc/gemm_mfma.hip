@@ -411,7 +411,7 @@ int vkas_gemm_nt_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* B
   // with the least zero padding (ties -> wider tile, fewer re-reads of A)
   static const int force = getenv("VKAS_NT_TILE") ? atoi(getenv("VKAS_NT_TILE")) : 0;
   int bn = 128;
-  bool big = M >= 65536;
+  bool big = M >= 16384;
   if (force) {
     big = force != 1;
     bn = force == 1 ? 128 : force;
@@ -443,7 +443,9 @@ static void launch_tn(const void* x, const vkas_conv_geom* g, const void* dy, lo
   // DOWN so that the last round is not a nearly empty tail
   const long resident = 256L * (WN * WK >= 8 ? 1 : 2);
   long splits = (3 * resident) / tiles;
-  const long max_splits = vkas_cdiv(M, 8 * TN_ROWS);
+  // every split adds a full copy of gw with fp32 atomics (~1.3 TB/s chip-wide): keep that below about half of the
+  // MFMA time, i.e. at most one split per ~2048 rows
+  const long max_splits = vkas_cdiv(M, 2048);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   if (splits > 65535) splits = 65535;
@@ -466,7 +468,7 @@ int vkas_gemm_tn_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* d
   int bn = 128;
   if (force) {
     bn = force;
-  } else if (M >= 65536 && K >= 256) {
+  } else if (M >= 16384 && K >= 256) {
     long best = vkas_cdiv(Np, 128) * 128;
     const int cand[2] = {192, 224};
     for (int c = 0; c < 2; ++c) {

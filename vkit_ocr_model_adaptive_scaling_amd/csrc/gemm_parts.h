@@ -45,7 +45,7 @@ __device__ __forceinline__ void epi_store4(const vkas_epilogue& e, long m, int n
       store4(out + m * e.ldo + n, v);
       float gv[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) gv[i] = gelu_f(v[i]);
+      for (int i = 0; i < 4; ++i) gv[i] = gelu_t<T>(v[i]);
       store4(reinterpret_cast<T*>(e.out2) + m * e.ldo2 + n, gv);
       break;
     }
@@ -63,7 +63,7 @@ __device__ __forceinline__ void epi_store4(const vkas_epilogue& e, long m, int n
       float h[4];
       load4(reinterpret_cast<const T*>(e.aux) + m * e.ldaux + n, h);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] *= dgelu_f(h[i]);
+      for (int i = 0; i < 4; ++i) v[i] *= dgelu_t<T>(h[i]);
       store4(out + m * e.ldo + n, v);
       break;
     }
@@ -114,7 +114,7 @@ __device__ __forceinline__ void epi_store8(const vkas_epilogue& e, long m, int n
       store8(out + m * e.ldo + n, v);
       float gv[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) gv[i] = gelu_f(v[i]);
+      for (int i = 0; i < 8; ++i) gv[i] = gelu_t<T>(v[i]);
       store8(reinterpret_cast<T*>(e.out2) + m * e.ldo2 + n, gv);
       break;
     }
@@ -133,7 +133,7 @@ __device__ __forceinline__ void epi_store8(const vkas_epilogue& e, long m, int n
       float h[8];
       load8(reinterpret_cast<const T*>(e.aux) + m * e.ldaux + n, h);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] *= dgelu_f(h[i]);
+      for (int i = 0; i < 8; ++i) v[i] *= dgelu_t<T>(h[i]);
       store8(out + m * e.ldo + n, v);
       break;
     }

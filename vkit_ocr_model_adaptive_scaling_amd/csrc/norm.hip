@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         float u = (v[r][i][c] - s[r]) * q[r] * gv[i][c] + bv[i][c];
-        if (act_gelu) u = gelu_f(u);
+        if (act_gelu) u = gelu_t<T>(u);
         o[c] = u;
       }
       store8(y + m * ldy + vi * 8, o);
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
           const bool cok = ok && vi < nvec && (vi * 8 + c < C);
           const float h = cok ? (xh[r][i][c] - mean[r]) * rstd[r] : 0.f;
           float gg = cok ? g[r][i][c] : 0.f;
-          if (act_gelu) gg *= dgelu_f(h * gm[i][c] + bt[i][c]);
+          if (act_gelu) gg *= dgelu_t<T>(h * gm[i][c] + bt[i][c]);
           xh[r][i][c] = h;
           g[r][i][c] = gg;
           dg[i][c] += gg * h;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void scale_res_bwd_kernel(const T* __restrict_
 }
 
 static inline long rows_per_block_for(long M, long quantum) {
-  long r = vkas_cdiv(M > 0 ? M : 1, 2048);
+  long r = vkas_cdiv(M > 0 ? M : 1, 1024);
   if (r < 256) r = 256;
   return vkas_cdiv(r, quantum) * quantum;
 }

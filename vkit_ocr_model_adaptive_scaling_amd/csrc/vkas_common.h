@@ -104,6 +104,32 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return cdf + x * pdf;
 }
 
+// bf16-storage variants: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below bf16 resolution) sharing one
+// exp between the cdf and the pdf; about a third of the instructions of erff + expf.  fp32 storage keeps the exact forms.
+__device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& pdf_x) {
+  const float ax = fabsf(x);
+  const float e = __expf(-0.5f * x * x);
+  const float t = __frcp_rn(fmaf(0.2316418881f, ax, 1.0f));  // 1 / (1 + p*|x|/sqrt2), p = 0.3275911
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float half_erfc = 0.5f * poly * e;                    // 0.5 * erfc(|x|/sqrt2)
+  cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
+  pdf_x = 0.39894228040143268f * e;
+}
+template <typename T> __device__ __forceinline__ float gelu_t(float x);
+template <> __device__ __forceinline__ float gelu_t<float>(float x) { return gelu_f(x); }
+template <> __device__ __forceinline__ float gelu_t<bf16_t>(float x) {
+  float cdf, pdf;
+  gelu_parts_fast(x, cdf, pdf);
+  return x * cdf;
+}
+template <typename T> __device__ __forceinline__ float dgelu_t(float x);
+template <> __device__ __forceinline__ float dgelu_t<float>(float x) { return dgelu_f(x); }
+template <> __device__ __forceinline__ float dgelu_t<bf16_t>(float x) {
+  float cdf, pdf;
+  gelu_parts_fast(x, cdf, pdf);
+  return fmaf(x, pdf, cdf);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
