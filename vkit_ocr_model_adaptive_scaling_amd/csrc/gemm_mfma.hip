@@ -238,9 +238,20 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wn = wave / WK, wk = wave % WK;
-  const int n0 = blockIdx.x * BNn;
-  const int kb = blockIdx.y * BKc;
-  const long mbeg = (long)blockIdx.z * rows_per_split;
+  // Work order: every XCD (private L2; workgroups are dealt round-robin over the 8 XCDs) gets a contiguous run of
+  // work items, all (n, k) tiles of one M split before the next split.  The tiles of a split walk the same dy / x
+  // rows at the same time, so each row is fetched from HBM about once per XCD and re-used from L2 by the other tiles
+  // (dy by every K tile, x by every N tile and by the K tiles of the other taps).  Speed only, never correctness.
+  const unsigned ntn = (unsigned)((Np + BNn - 1) / BNn), ntk = (unsigned)((K + BKc - 1) / BKc);
+  const unsigned total = gridDim.x;
+  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const unsigned q8 = total >> 3, r8 = total & 7u;
+  const unsigned work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  const unsigned tile = work % (ntn * ntk);
+  const int n0 = (int)(tile % ntn) * BNn;
+  const int kb = (int)(tile / ntn) * BKc;
+  const bool first_k_tile = tile / ntn == 0;
+  const long mbeg = (long)(work / (ntn * ntk)) * rows_per_split;
   const long mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
 
   // dy staging: chunk index tid + NTHR*i -> (row, col)
@@ -322,7 +333,7 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
 #pragma unroll
     for (int j = 0; j < TK; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // bias gradient = column sums of dy: the first K block's wk == 0 waves add up the dy fragments they already hold
-  const bool do_bias = gb != nullptr && blockIdx.y == 0 && wk == 0;
+  const bool do_bias = gb != nullptr && first_k_tile && wk == 0;
   float bsum[TNn];
 #pragma unroll
   for (int i = 0; i < TNn; ++i) bsum[i] = 0.f;
@@ -439,20 +450,34 @@ static void launch_tn(const void* x, const vkas_conv_geom* g, const void* dy, lo
                       float* gb, hipStream_t st) {
   constexpr int BNn = WN * TNn * 16, BKc = WK * TK * 16;
   const long tiles = vkas_cdiv(Np, BNn) * vkas_cdiv(K, BKc);
-  // whole rounds of resident workgroups: 256 CUs x (1 block of 8 waves | 2 blocks of 4 waves) x 3 rounds, rounded
-  // DOWN so that the last round is not a nearly empty tail
+  // Splits over M.  Bounds: (a) about 3 rounds of resident workgroups (256 CUs x 1 block of 8 waves | 2 blocks of 4);
+  // (b) every split adds a full copy of gw with fp32 atomics (~1.3 TB/s chip-wide): at most one split per ~2048
+  // rows keeps that below about half of the MFMA time.  Then prefer a multiple of 8 (whole splits per XCD, see the
+  // kernel's work order) whose per-XCD block count fills whole rounds of that XCD's 32 CUs.
   const long resident = 256L * (WN * WK >= 8 ? 1 : 2);
   long splits = (3 * resident) / tiles;
-  // every split adds a full copy of gw with fp32 atomics (~1.3 TB/s chip-wide): keep that below about half of the
-  // MFMA time, i.e. at most one split per ~2048 rows
   const long max_splits = vkas_cdiv(M, 2048);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
+  if (splits >= 8) {
+    const long per_xcd_slots = resident / 8;
+    long best = 8;
+    double best_eff = 0.0;
+    for (long s8 = 8; s8 <= 4 * splits && s8 <= max_splits; s8 += 8) {
+      const long blocks = (s8 / 8) * tiles;
+      const double eff = (double)blocks / (double)(vkas_cdiv(blocks, per_xcd_slots) * per_xcd_slots);
+      if (eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && labs(s8 - splits) < labs(best - splits))) {
+        best_eff = eff;
+        best = s8;
+      }
+    }
+    splits = best;
+  }
   if (splits > 65535) splits = 65535;
   long rows = vkas_cdiv(M, splits);
   rows = vkas_cdiv(rows, TN_ROWS) * TN_ROWS;
   splits = vkas_cdiv(M, rows);
-  dim3 grid((unsigned)vkas_cdiv(Np, BNn), (unsigned)vkas_cdiv(K, BKc), (unsigned)splits);
+  dim3 grid((unsigned)(tiles * splits));
   gemm_tn_mfma_kernel<WN, WK, TNn, TK><<<grid, WN * WK * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy, Np, M,
                                                                      K, rows, gw, gb);
 }
