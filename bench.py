@@ -184,18 +184,35 @@ def main():
             for key, (n_, ms_, fl_) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                 print(f'[bench] {key[0]:14s} {key[1]:8d} {key[2]:5d} {key[3]:5d} {n_ / args.steps:6.1f} '
                       f'{ms_ / args.steps:8.3f} {fl_ / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0:8.1f}', file=sys.stderr)
-        dom = 'gemm_nt_mfma' if dtype == torch.bfloat16 else 'gemm_nt_simple'
+        # dominant kernel = the instantiation with the largest share of the timed region
+        dom = max(summ, key=lambda k: summ[k]['ms']) if summ else 'none'
         d = summ.get(dom, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
         achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
-        roof = {'bound': 'mfma', 'kernel': 'gemm_nt_mfma_kernel (implicit-GEMM conv fwd/dgrad, bf16 16x16x32 MFMA)',
+        names = {'gemm_nt_mfma<256x192>': 'gemm_nt_mfma_kernel<4,2,4,6>', 'gemm_nt_mfma<256x224>': 'gemm_nt_mfma_kernel<4,2,4,7>',
+                 'gemm_nt_mfma<256x128>': 'gemm_nt_mfma_kernel<4,2,4,4>', 'gemm_nt_mfma<128x128>': 'gemm_nt_mfma_kernel<2,2,4,4>',
+                 'gemm_tn_mfma<224x256>': 'gemm_tn_mfma_kernel<2,4,7,4>', 'gemm_tn_mfma<192x256>': 'gemm_tn_mfma_kernel<2,4,6,4>',
+                 'gemm_tn_mfma<128x128>': 'gemm_tn_mfma_kernel<2,2,4,4>'}
+        traffic = None
+        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        default_cfg = (args.size == 1024 and args.batch == 8 and args.dtype == 'bf16')
+        if default_cfg and os.path.exists(pmc_path):  # per-launch HBM bytes from the rocprofv3 --pmc passes of this command
+            pmc = json.load(open(pmc_path)).get(names.get(dom, dom))
+            if pmc:
+                traffic = pmc['bytes_per_launch']
+        all_gemm_flops = sum(v['flops'] for v in summ.values())
+        all_gemm_ms = sum(v['ms'] for v in summ.values())
+        roof = {'bound': 'mfma', 'kernel': f'{names.get(dom, dom)} (implicit-GEMM conv, bf16 v_mfma_f32_16x16x32_bf16)',
                 'achieved': round(achieved, 2), 'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), 'traffic': None,
+                'frac': round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), 'traffic': traffic,
                 'launches_per_step': d['launches'] / max(args.steps, 1),
                 'avg_launch_ms': round(d['ms'] / max(d['launches'], 1), 4),
                 'flops_per_launch': d['flops'] / max(d['launches'], 1),
                 'share_of_step_time': round(d['ms'] / (1000.0 * elapsed), 3),
-                'other_kernels': {k: {'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else 0.0,
-                                      'share_of_step_time': round(v['ms'] / (1000.0 * elapsed), 3)}
+                'all_mfma_kernels': {'tflops': round(all_gemm_flops / (all_gemm_ms * 1e-3) / 1e12, 2) if all_gemm_ms > 0 else 0.0,
+                                     'share_of_step_time': round(all_gemm_ms / (1000.0 * elapsed), 3)},
+                'other_kernels': {names.get(k, k): {'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else 0.0,
+                                                    'avg_launch_ms': round(v['ms'] / max(v['launches'], 1), 4),
+                                                    'share_of_step_time': round(v['ms'] / (1000.0 * elapsed), 3)}
                                   for k, v in summ.items() if k != dom}}
         out = {'metric': 'images/sec fwd+bwd @1024x1024 bf16 (train step: rough+precise passes, losses, backward, '
                          'clip, AdamW)', 'value': round(images / (elapsed / args.steps), 3), 'unit': 'images/s',

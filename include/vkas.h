@@ -104,6 +104,10 @@ int vkas_conv_gemm_fwd(const void* x, const vkas_conv_geom* g, const void* Bw, i
  * fp32 atomics. */
 int vkas_conv_gemm_wgrad(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
                          float* gb, int dtype, void* stream);
+/* profiling aid: tile configuration a bf16 call of these sizes runs.  fwd (wgrad == 0): 1 = 128x128 (4 waves), else the
+ * N extent 128 / 192 / 224 of the 256-row 8-wave tile; wgrad: N extent 128 (4 waves) or 192 / 224 (8 waves); 0 when the
+ * plain fp32-FMA kernels are forced (VKAS_GEMM=simple). */
+int vkas_conv_gemm_tile(int wgrad, long M, int Np, int K);
 /* column sums: out[n] (+)= sum_m y[m][n]   (bias gradients) */
 int vkas_colsum(const void* y, long ld, long M, int Np, float* out, int accumulate, float* ws, size_t ws_bytes,
                 int dtype, void* stream);

@@ -9,6 +9,9 @@ int vkas_gemm_tn_simple(const void*, const vkas_conv_geom*, const void*, long, i
 int vkas_gemm_nt_mfma_bf16(const void*, const vkas_conv_geom*, const void*, int, const vkas_epilogue*, hipStream_t);
 int vkas_gemm_tn_mfma_bf16(const void*, const vkas_conv_geom*, const void*, long, int, float*, float*, hipStream_t);
 
+int vkas_gemm_nt_tile_choice(long M, int Np);
+int vkas_gemm_tn_tile_choice(long M, int Np, int K);
+
 static thread_local char g_err[512] = "";
 
 void vkas_set_error(const char* fmt, ...) {
@@ -80,6 +83,12 @@ extern "C" int vkas_conv_gemm_fwd(const void* x, const vkas_conv_geom* g, const 
                "vkas_conv_gemm_fwd: patch grid does not match the GEMM rows");
   if (dtype == VKAS_BF16 && !force_simple()) return vkas_gemm_nt_mfma_bf16(x, g, Bw, Np, epi, vkas_stream(stream));
   return vkas_gemm_nt_simple(x, g, Bw, Np, epi, dtype, vkas_stream(stream));
+}
+
+// Which kernel instantiation a bf16 call with these sizes runs (profiling aid; the names match rocprofv3's).
+extern "C" int vkas_conv_gemm_tile(int wgrad, long M, int Np, int K) {
+  if (force_simple()) return 0;
+  return wgrad ? vkas_gemm_tn_tile_choice(M, Np, K) : vkas_gemm_nt_tile_choice(M, Np);
 }
 
 extern "C" int vkas_conv_gemm_wgrad(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np,

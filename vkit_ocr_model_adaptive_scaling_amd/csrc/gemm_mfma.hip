@@ -413,30 +413,34 @@ static void launch_nt(const void* x, const vkas_conv_geom* g, const void* Bw, in
   gemm_nt_mfma_kernel<WM, WN, TM, TN><<<grid, WM * WN * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)Bw, Np, M, K, *e);
 }
 
+// Tile choice of the NT kernel: returns 1 for the 4-wave 128x128 tile, else the N extent (128 / 192 / 224) of the
+// 8-wave 256-row tile.  256-row tiles once there is enough work to fill the chip with them; N extent = the candidate
+// with the least zero padding (ties -> wider tile, fewer re-reads of A).
+int vkas_gemm_nt_tile_choice(long M, int Np) {
+  static const int force = getenv("VKAS_NT_TILE") ? atoi(getenv("VKAS_NT_TILE")) : 0;
+  if (force) return force;
+  if (M < 16384) return 1;
+  long best = -1;
+  int bn = 128;
+  const int cand[3] = {224, 192, 128};
+  for (int c = 0; c < 3; ++c) {
+    const long padded = vkas_cdiv(Np, cand[c]) * cand[c];
+    if (best < 0 || padded < best) {
+      best = padded;
+      bn = cand[c];
+    }
+  }
+  return bn;
+}
+
 int vkas_gemm_nt_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* Bw, int Np, const vkas_epilogue* e,
                            hipStream_t st) {
   const long M = (long)g->B * g->Hout * g->Wout;
   const int K = g->KH * g->KW * g->Cp;
   if (M == 0) return VKAS_OK;
-  // tile choice: 256-row tiles once there is enough work to fill the chip with them; N extent = the candidate
-  // with the least zero padding (ties -> wider tile, fewer re-reads of A)
-  static const int force = getenv("VKAS_NT_TILE") ? atoi(getenv("VKAS_NT_TILE")) : 0;
-  int bn = 128;
-  bool big = M >= 16384;
-  if (force) {
-    big = force != 1;
-    bn = force == 1 ? 128 : force;
-  } else if (big) {
-    long best = -1;
-    const int cand[3] = {224, 192, 128};
-    for (int c = 0; c < 3; ++c) {
-      const long padded = vkas_cdiv(Np, cand[c]) * cand[c];
-      if (best < 0 || padded < best) {
-        best = padded;
-        bn = cand[c];
-      }
-    }
-  }
+  const int choice = vkas_gemm_nt_tile_choice(M, Np);
+  const bool big = choice != 1;
+  const int bn = big ? choice : 128;
   if (!big) launch_nt<2, 2, 4, 4>(x, g, Bw, Np, M, K, e, st);
   else if (bn == 224) launch_nt<4, 2, 4, 7>(x, g, Bw, Np, M, K, e, st);
   else if (bn == 192) launch_nt<4, 2, 4, 6>(x, g, Bw, Np, M, K, e, st);
@@ -482,18 +486,13 @@ static void launch_tn(const void* x, const vkas_conv_geom* g, const void* dy, lo
                                                                      K, rows, gw, gb);
 }
 
-int vkas_gemm_tn_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
-                           float* gb, hipStream_t st) {
-  const long M = (long)g->B * g->Hout * g->Wout;
-  const int K = g->KH * g->KW * g->Cp;
-  if (M == 0) return VKAS_OK;
-  // 8-wave tiles (224 or 192 output channels x 256 K columns) when there is enough work and K is wide enough; the
-  // N extent is the candidate with the least zero padding
+// Tile choice of the TN (wgrad) kernel: N extent 128 (4 waves, 128 K columns) or 192 / 224 (8 waves, 256 K columns):
+// 8-wave tiles when there is enough work and K is wide enough; N extent = least zero padding.
+int vkas_gemm_tn_tile_choice(long M, int Np, int K) {
   static const int force = getenv("VKAS_TN_TILE") ? atoi(getenv("VKAS_TN_TILE")) : 0;
+  if (force) return force;
   int bn = 128;
-  if (force) {
-    bn = force;
-  } else if (M >= 16384 && K >= 256) {
+  if (M >= 16384 && K >= 256) {
     long best = vkas_cdiv(Np, 128) * 128;
     const int cand[2] = {192, 224};
     for (int c = 0; c < 2; ++c) {
@@ -504,6 +503,15 @@ int vkas_gemm_tn_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* d
       }
     }
   }
+  return bn;
+}
+
+int vkas_gemm_tn_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
+                           float* gb, hipStream_t st) {
+  const long M = (long)g->B * g->Hout * g->Wout;
+  const int K = g->KH * g->KW * g->Cp;
+  if (M == 0) return VKAS_OK;
+  const int bn = vkas_gemm_tn_tile_choice(M, Np, K);
   if (bn == 224) launch_tn<2, 4, 7, 4>(x, g, dy, lddy, Np, M, K, gw, gb, st);
   else if (bn == 192) launch_tn<2, 4, 6, 4>(x, g, dy, lddy, Np, M, K, gw, gb, st);
   else launch_tn<2, 2, 4, 4>(x, g, dy, lddy, Np, M, K, gw, gb, st);

@@ -150,7 +150,11 @@ def conv_gemm(x: torch.Tensor, geom: ConvGeom, Bw: torch.Tensor, Np: int, out: t
         # algorithmic FLOPs use the logical (unpadded) N and K when the caller knows them
         M = geom.B * geom.Hout * geom.Wout
         N, K = nk if nk is not None else (Np, geom.KH * geom.KW * geom.Cp)
-        kind = ('gemm_nt_mfma' if x.dtype == torch.bfloat16 else 'gemm_nt_simple')
+        if x.dtype == torch.bfloat16:
+            t = lib.vkas_conv_gemm_tile(0, M, Np, geom.KH * geom.KW * geom.Cp)
+            kind = 'gemm_nt_mfma<%s>' % ('128x128' if t == 1 else '256x%d' % t)
+        else:
+            kind = 'gemm_nt_simple'
         return _timed(kind, x, 2.0 * M * N * K, M, N, K,
                       lambda: _conv_gemm(x, geom, Bw, Np, out, mode, bias, out2, aux, colscale, rowscale, rows_per_image,
                                          patch, patch_hw, patch_Cp))
@@ -184,7 +188,11 @@ def conv_wgrad(x: torch.Tensor, geom: ConvGeom, dy: torch.Tensor, Np: int, nk=No
         check(lib.vkas_conv_gemm_wgrad(_p(x), ctypes.byref(geom), _p(dy), act_ld(dy), Np, _p(gw), _p(gb), _dt(x),
                                        _stream()), 'conv_gemm_wgrad')
         return (gw, gb) if with_bias else gw
-    kind = 'gemm_tn_mfma' if x.dtype == torch.bfloat16 else 'gemm_tn_simple'
+    if x.dtype == torch.bfloat16:
+        t = lib.vkas_conv_gemm_tile(1, M, Np, K)
+        kind = 'gemm_tn_mfma<%s>' % ('128x128' if t == 128 else '%dx256' % t)
+    else:
+        kind = 'gemm_tn_simple'
     N, Kl = nk if nk is not None else (Np, K)
     return _timed(kind, x, 2.0 * M * N * Kl, M, N, Kl, run)
 
