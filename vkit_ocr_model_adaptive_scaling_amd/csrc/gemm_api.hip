@@ -103,7 +103,7 @@ extern "C" int vkas_conv_gemm_wgrad(const void* x, const vkas_conv_geom* g, cons
 
 // ---- column sums ------------------------------------------------------------------------------------
 namespace {
-static inline long cs_rows_per_block(long M) { long r = vkas_cdiv(M > 0 ? M : 1, 1024); return r < 256 ? 256 : r; }
+static inline long cs_rows_per_block(long M) { long r = vkas_cdiv(M > 0 ? M : 1, 1024); return r < 32 ? 32 : r; }
 
 // partial[blk][c] = sum over this block's rows of y[m][c]; thread = one 8-channel vector, rows strided.
 template <typename T>

@@ -290,9 +290,11 @@ __global__ __launch_bounds__(256) void scale_res_bwd_kernel(const T* __restrict_
   }
 }
 
+// about 1024 workgroups per launch (4 per CU); never fewer than 32 rows per workgroup so that small feature maps
+// (stage 2/3: 8K-32K pixels) still spread over the whole chip
 static inline long rows_per_block_for(long M, long quantum) {
   long r = vkas_cdiv(M > 0 ? M : 1, 1024);
-  if (r < 256) r = 256;
+  if (r < 32) r = 32;
   return vkas_cdiv(r, quantum) * quantum;
 }
 
