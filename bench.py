@@ -156,6 +156,7 @@ def main():
     for _ in range(args.steps):
         losses = step(rough, precise, lr=cosine_warm_restarts_lr(it / 1000.0, 8e-4, 8e-6, 10, 10))
         it += 1
+    enqueue = time.perf_counter() - t0  # host time to enqueue the timed steps (no sync inside a step)
     sync()
     elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
@@ -168,8 +169,8 @@ def main():
         raise SystemExit('non-finite loss in the timed region')
 
     if rank == 0:
-        print(f'[bench] {args.steps} steps in {elapsed:.3f} s on {world} GPU(s); losses {rl:.4f} {pl:.4f}', file=sys.stderr,
-              flush=True)
+        print(f'[bench] {args.steps} steps in {elapsed:.3f} s on {world} GPU(s); host enqueue {enqueue:.3f} s; '
+              f'losses {rl:.4f} {pl:.4f}', file=sys.stderr, flush=True)
         ms = 1000.0 * elapsed / args.steps
         images = 2 * args.batch * world  # one rough + one precise batch per rank per step
         summ = timer.summary()
