@@ -192,3 +192,53 @@ def test_cpu_input_fails_loudly():
     m = ConvNext(3, ((16, 1), (32, 1)), False)
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 32, 32))
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=IDS)
+def test_config2_tiny_backbone_640_batch4(dtype):
+    """BASELINE.json configs[1]: ConvNeXt-Tiny backbone forward, 640x640, batch 4 (bf16 on the GPU) vs the oracle on the
+    host with the same seeded weights (O(1) layer scale so the residual branches count)."""
+    from vkit_ocr_model_adaptive_scaling_amd.model import ConvNext, set_compute_dtype
+    m = seed_module(ConvNext.create_tiny(), 61, 0.05)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.from_numpy(recipe.image(61, (4, 3, 640, 640))).float()
+    with torch.no_grad():
+        ref = O.convnext_forward(sd, x)
+        set_compute_dtype(m.cuda().eval(), dtype)
+        feats = m(x.cuda())
+    assert [tuple(f.shape) for f in feats] == [(4, 96, 160, 160), (4, 192, 80, 80), (4, 384, 40, 40), (4, 768, 20, 20)]
+    errs = [rel_err(f, r) for f, r in zip(feats, ref)]
+    print('config #2 backbone fwd rel err', dtype, errs)
+    assert max(errs) < FWD_TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=IDS)
+def test_base_model_nonsquare_vs_oracle(dtype):
+    """configs[4] ingredients that exist this round: ConvNeXt-Base widths (128..1024, neck 512, head inner 256..258) on a
+    non-square input whose sides are different multiples of 32 (stage-3 map 3 x 5): both passes, forward + one loss
+    backward, vs the oracle.  (fp16 and the inference-time resize loop are not built yet.)"""
+    from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
+                                                           AdaptiveScalingNeckHeadType)
+    model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.BASE, AdaptiveScalingNeckHeadType.UPERNEXT),
+                            compute_dtype=dtype)
+    seed_module(model, 62, 0.04)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    x = torch.from_numpy(recipe.image(62, (1, 3, 96, 160))).float()
+    ref_r = O.forward_rough(sd, x, 'upernext')
+    ref_p = O.forward_precise(sd, x, 'upernext')
+    (ref_r[0].sum() + ref_p[2].sum()).backward()
+    model.cuda().eval()
+    out_r = model.forward_rough(x.cuda())
+    out_p = model.forward_precise(x.cuda())
+    for o, r in zip(out_r + out_p, ref_r + ref_p):
+        assert tuple(o.shape) == tuple(r.shape)
+        assert rel_err(o, r.detach()) < FWD_TOL[dtype]
+    (out_r[0].sum() + out_p[2].sum()).backward()
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for k in ('backbone.blocks.3.layers.2.block.3.weight', 'backbone.blocks.2.layers.26.block.0.weight',
+              'backbone.blocks.0.ln.1.weight', 'rough_neck.step1_conv_blocks.3.final_conv_block.0.weight',
+              'precise_char_corner_angle_head.step1_conv3x3.0.weight', 'backbone.stem.0.weight'):
+        worst = max(worst, rel_err(params[k].grad, sd[k].grad))
+    print('Base non-square grad rel err', dtype, worst)
+    assert worst < GRAD_TOL[dtype] * (1 if dtype == torch.float32 else 2)

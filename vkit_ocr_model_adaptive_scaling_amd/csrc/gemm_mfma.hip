@@ -24,10 +24,15 @@ __device__ __forceinline__ int swz_off(int row, int chunk) {  // element offset 
 // WM x WN waves, each owning TM x TN 16x16 MFMA tiles: block tile = (WM*TM*16) x (WN*TN*16), BK = 64.
 // Instantiated as 128x128 (4 waves), 256x128, 256x192 and 256x224 (8 waves, 2 per SIMD): the wide tiles cut
 // the zero-padding waste on N = 192..200 (head convs) and raise the MFMA : LDS-traffic ratio.
-template <int WM, int WN, int TM, int TN>
+//
+// BUF = true (every operand < 4 GiB, the normal case): operands are fetched with raw buffer loads.  The hardware
+// range check returns zeros for an out-of-range offset, so zero padding / tile tails cost one v_cndmask on a 32-bit
+// byte offset instead of a divergent branch, and the per-K-tile address arithmetic shrinks to an add per row: the
+// main loop had ~3.8 VALU instructions per MFMA and was issue-bound; this path has < 1.
+template <int WM, int WN, int TM, int TN, bool BUF>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
                                                                   const bf16_t* __restrict__ Bw, int Np, long M, int K,
-                                                                  vkas_epilogue e) {
+                                                                  vkas_epilogue e, unsigned a_bytes, unsigned b_bytes) {
   constexpr int NTHR = WM * WN * 64;
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int RSTEP = NTHR / 8;                   // rows covered by one staging pass
@@ -54,7 +59,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
   const int cc = tid & 7;
   const int sr = tid >> 3;
   int a_by[ACH], a_y[ACH], a_x[ACH];  // b*Hin, oy*stride-pad, ox*stride-pad ; a_by < 0 => row out of range
+  unsigned a_base[ACH];                // BUF: byte offset of pixel (b, a_y, a_x), modulo 2^32 (a_y / a_x may be -pad)
   const bf16_t* b_ptr[BCH];
+  unsigned b_base[BCH];
   bool b_ok[BCH];
 #pragma unroll
   for (int i = 0; i < ACH; ++i) {
@@ -62,6 +69,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
     a_by[i] = rc.ok ? rc.b * g.Hin : -1;
     a_y[i] = rc.oy * g.stride - g.pad;
     a_x[i] = rc.ox * g.stride - g.pad;
+    a_base[i] = (((unsigned)(rc.b * g.Hin + a_y[i]) * (unsigned)g.Win + (unsigned)a_x[i]) * (unsigned)g.ldx) << 1;
   }
 #pragma unroll
   for (int i = 0; i < BCH; ++i) {
@@ -69,6 +77,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
     const int n = n0 + r;
     b_ok[i] = r < BN && n < Np;
     b_ptr[i] = Bw + (long)(b_ok[i] ? n : 0) * K;
+    b_base[i] = ((unsigned)(b_ok[i] ? n : 0) * (unsigned)K) << 1;
   }
   // running decode of this thread's k chunk: k = kt*BK + cc*8 -> (ky, kx, c)
   int kcur = cc * 8;
@@ -77,25 +86,48 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
     c_in -= g.Cp;
     if (++kx == g.KW) { kx = 0; ++ky; }
   }
+  __amdgpu_buffer_rsrc_t rs_a, rs_b;
+  if constexpr (BUF) {
+    rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)x, (short)0, (int)a_bytes, 0x00020000);
+    rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)Bw, (short)0, (int)b_bytes, 0x00020000);
+  }
 
   bf16x8 ra[ACH], rb[BCH];
   auto load_tile = [&]() {
     const bool k_ok = kcur < K;
+    if constexpr (BUF) {
+      constexpr unsigned OOB = 0xFFFFFFF0u;  // beyond any descriptor: the load returns zeros
+      const unsigned t_off = (((unsigned)(ky * g.Win + kx) * (unsigned)g.ldx) + (unsigned)c_in) << 1;
 #pragma unroll
-    for (int i = 0; i < ACH; ++i) {
-      bf16x8 va = {0, 0, 0, 0, 0, 0, 0, 0};
-      const int iy = a_y[i] + ky, ix = a_x[i] + kx;
-      if (k_ok && a_by[i] >= 0 && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win) {
-        const long off = ((long)(a_by[i] + iy) * g.Win + ix) * (long)g.ldx + c_in;
-        va = *reinterpret_cast<const bf16x8*>(x + off);
+      for (int i = 0; i < ACH; ++i) {
+        const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+        const bool ok = k_ok && a_by[i] >= 0 && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_a, ok ? a_base[i] + t_off : OOB, 0, 0);
+        ra[i] = __builtin_bit_cast(bf16x8, v);
       }
-      ra[i] = va;
-    }
+      const unsigned kb2 = (unsigned)kcur << 1;
 #pragma unroll
-    for (int i = 0; i < BCH; ++i) {
-      bf16x8 vb = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (k_ok && b_ok[i]) vb = *reinterpret_cast<const bf16x8*>(b_ptr[i] + kcur);
-      rb[i] = vb;
+      for (int i = 0; i < BCH; ++i) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (k_ok && b_ok[i]) ? b_base[i] + kb2 : OOB, 0, 0);
+        rb[i] = __builtin_bit_cast(bf16x8, v);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < ACH; ++i) {
+        bf16x8 va = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+        if (k_ok && a_by[i] >= 0 && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win) {
+          const long off = ((long)(a_by[i] + iy) * g.Win + ix) * (long)g.ldx + c_in;
+          va = *reinterpret_cast<const bf16x8*>(x + off);
+        }
+        ra[i] = va;
+      }
+#pragma unroll
+      for (int i = 0; i < BCH; ++i) {
+        bf16x8 vb = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (k_ok && b_ok[i]) vb = *reinterpret_cast<const bf16x8*>(b_ptr[i] + kcur);
+        rb[i] = vb;
+      }
     }
     // advance to the next K tile
     kcur += BK;
@@ -410,7 +442,16 @@ static void launch_nt(const void* x, const vkas_conv_geom* g, const void* Bw, in
                       const vkas_epilogue* e, hipStream_t st) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   dim3 grid((unsigned)(vkas_cdiv(M, BM) * vkas_cdiv(Np, BN)));
-  gemm_nt_mfma_kernel<WM, WN, TM, TN><<<grid, WM * WN * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)Bw, Np, M, K, *e);
+  // bytes spanned by the operands (x may be a channel slice: last pixel ends after Cp of its ld channels)
+  const long a_bytes = (((long)g->B * g->Hin * g->Win - 1) * g->ldx + g->Cp) * 2;
+  const long b_bytes = (long)Np * K * 2;
+  static const bool no_buf = getenv("VKAS_NT_NOBUF") != nullptr;
+  if (!no_buf && a_bytes < 0xFFFFFFF0L && b_bytes < 0xFFFFFFF0L)
+    gemm_nt_mfma_kernel<WM, WN, TM, TN, true><<<grid, WM * WN * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)Bw, Np, M, K,
+                                                                            *e, (unsigned)a_bytes, (unsigned)b_bytes);
+  else
+    gemm_nt_mfma_kernel<WM, WN, TM, TN, false><<<grid, WM * WN * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)Bw, Np, M, K,
+                                                                             *e, 0u, 0u);
 }
 
 // Tile choice of the NT kernel: returns 1 for the 4-wave 128x128 tile, else the N extent (128 / 192 / 224) of the
