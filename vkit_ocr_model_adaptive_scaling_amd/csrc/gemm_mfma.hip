@@ -129,12 +129,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
         rb[i] = vb;
       }
     }
-    // advance to the next K tile
+    // advance to the next K tile (branch-free when a tap holds at least one K tile of channels)
     kcur += BK;
     c_in += BK;
-    while (c_in >= g.Cp) {
-      c_in -= g.Cp;
-      if (++kx == g.KW) { kx = 0; ++ky; }
+    if (g.Cp >= BK) {  // wave-uniform
+      const bool wrap = c_in >= g.Cp;
+      c_in -= wrap ? g.Cp : 0;
+      kx += wrap ? 1 : 0;
+      const bool wrap_x = kx == g.KW;
+      kx = wrap_x ? 0 : kx;
+      ky += wrap_x ? 1 : 0;
+    } else {
+      while (c_in >= g.Cp) {
+        c_in -= g.Cp;
+        if (++kx == g.KW) { kx = 0; ++ky; }
+      }
     }
   };
   auto store_tile = [&](int buf) {
@@ -250,11 +259,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int mbase, int col
 // channels x (WK*TK*16) K columns and walks its M split 64 rows at a time.  LDS tiles stay [row][col] with rows
 // padded by 16 elements (row pitch = odd multiple of 32 B => the 8 rows a half-wave touches in one transposing
 // read sit on distinct bank groups).
-template <int WN, int WK, int TNn, int TK>
+template <int WN, int WK, int TNn, int TK, bool BUF>
 __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
                                                                   const bf16_t* __restrict__ dy, long lddy, int Np,
                                                                   long M, int K, long rows_per_split,
-                                                                  float* __restrict__ gw, float* __restrict__ gb) {
+                                                                  float* __restrict__ gw, float* __restrict__ gb,
+                                                                  unsigned x_bytes, unsigned dy_bytes) {
   constexpr int NTHR = WN * WK * 64;
   constexpr int BNn = WN * TNn * 16, BKc = WK * TK * 16;
   constexpr int LDD = BNn + 16, LDX = BKc + 16;
@@ -289,6 +299,7 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
   // dy staging: chunk index tid + NTHR*i -> (row, col)
   int d_row[DCH], d_lds[DCH];
   const bf16_t* d_ptr[DCH];
+  unsigned d_off[DCH];  // BUF: running byte offset of this chunk
   bool d_ok[DCH];
 #pragma unroll
   for (int i = 0; i < DCH; ++i) {
@@ -298,6 +309,7 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
     d_ok[i] = row < TN_ROWS && n0 + col * 8 < Np;
     d_lds[i] = (row < TN_ROWS ? row : 0) * LDD + col * 8;
     d_ptr[i] = dy + (mbeg + (row < TN_ROWS ? row : 0)) * lddy + n0 + col * 8;
+    d_off[i] = (unsigned)(((mbeg + (row < TN_ROWS ? row : 0)) * lddy + n0 + col * 8) << 1);
   }
   // x staging: fixed chunk column -> fixed tap (ky, kx) and channel offset; rows xr + XSTEP*i
   const int xc = tid % CPRX;
@@ -320,24 +332,43 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
     r_y[i] = rc.oy;
     r_x[i] = rc.ox;
   }
+  __amdgpu_buffer_rsrc_t rs_x, rs_d;
+  if constexpr (BUF) {
+    rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, (short)0, (int)x_bytes, 0x00020000);
+    rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)dy, (short)0, (int)dy_bytes, 0x00020000);
+  }
+  const unsigned d_step = (unsigned)((long)TN_ROWS * lddy * 2);
+  const unsigned c_in2 = (unsigned)c_in << 1;
 
   bf16x8 rd[DCH], rx[XCH];
   long mcur = mbeg;
   auto load_tile = [&]() {
+    constexpr unsigned OOB = 0xFFFFFFF0u;  // beyond any descriptor: the buffer load returns zeros
 #pragma unroll
     for (int i = 0; i < DCH; ++i) {
-      bf16x8 vd = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (d_ok[i] && mcur + d_row[i] < mend) vd = *reinterpret_cast<const bf16x8*>(d_ptr[i]);
-      rd[i] = vd;
-      d_ptr[i] += (long)TN_ROWS * lddy;
+      const bool ok = d_ok[i] && mcur + d_row[i] < mend;
+      if constexpr (BUF) {
+        rd[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_d, ok ? d_off[i] : OOB, 0, 0));
+        d_off[i] += d_step;
+      } else {
+        bf16x8 vd = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) vd = *reinterpret_cast<const bf16x8*>(d_ptr[i]);
+        rd[i] = vd;
+        d_ptr[i] += (long)TN_ROWS * lddy;
+      }
     }
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
-      bf16x8 vx = {0, 0, 0, 0, 0, 0, 0, 0};
       const int iy = r_y[i] * g.stride + kyo, ix = r_x[i] * g.stride + kxo;
-      if (k_ok && mcur + xr + XSTEP * i < mend && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win)
-        vx = *reinterpret_cast<const bf16x8*>(x + (((long)r_b[i] * g.Hin + iy) * g.Win + ix) * (long)g.ldx + c_in);
-      rx[i] = vx;
+      const bool ok = k_ok && mcur + xr + XSTEP * i < mend && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+      if constexpr (BUF) {
+        const unsigned off = ((((unsigned)(r_b[i] * g.Hin + iy) * (unsigned)g.Win + (unsigned)ix) * (unsigned)g.ldx) << 1) + c_in2;
+        rx[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? off : OOB, 0, 0));
+      } else {
+        bf16x8 vx = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) vx = *reinterpret_cast<const bf16x8*>(x + (((long)r_b[i] * g.Hin + iy) * g.Win + ix) * (long)g.ldx + c_in);
+        rx[i] = vx;
+      }
       r_x[i] += TN_ROWS;  // advance this row by TN_ROWS output pixels, no divisions
       while (r_x[i] >= g.Wout) {
         r_x[i] -= g.Wout;
@@ -523,8 +554,16 @@ static void launch_tn(const void* x, const vkas_conv_geom* g, const void* dy, lo
   rows = vkas_cdiv(rows, TN_ROWS) * TN_ROWS;
   splits = vkas_cdiv(M, rows);
   dim3 grid((unsigned)(tiles * splits));
-  gemm_tn_mfma_kernel<WN, WK, TNn, TK><<<grid, WN * WK * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy, Np, M,
-                                                                     K, rows, gw, gb);
+  const long x_bytes = (((long)g->B * g->Hin * g->Win - 1) * g->ldx + g->Cp) * 2;
+  const long dy_bytes = ((M - 1) * lddy + Np) * 2;
+  static const bool no_buf = getenv("VKAS_TN_NOBUF") != nullptr;
+  if (!no_buf && x_bytes < 0xFFFFFFF0L && dy_bytes < 0xFFFFFFF0L)
+    gemm_tn_mfma_kernel<WN, WK, TNn, TK, true><<<grid, WN * WK * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy, Np,
+                                                                             M, K, rows, gw, gb, (unsigned)x_bytes,
+                                                                             (unsigned)dy_bytes);
+  else
+    gemm_tn_mfma_kernel<WN, WK, TNn, TK, false><<<grid, WN * WK * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy,
+                                                                              Np, M, K, rows, gw, gb, 0u, 0u);
 }
 
 // Tile choice of the TN (wgrad) kernel: N extent 128 (4 waves, 128 K columns) or 192 / 224 (8 waves, 256 K columns):
