@@ -46,6 +46,9 @@ extern "C" {
 #define VKAS_EPI_DGELU 3      /* out = (acc) * gelu'(aux)                                     backward of helper.py:100 */
 #define VKAS_EPI_ADD 4        /* out = acc + bias + aux                                       gradient accumulation */
 #define VKAS_EPI_PATCH 5      /* out scattered to non-overlapping kxk patches: dgrad of helper.py:43-58 */
+#define VKAS_EPI_HEAD 6       /* fused head tail: out = z = acc + bias (pre-LN, kept for backward); per pixel
+                               * LayerNorm -> GELU -> Linear(C -> 1..4) in the epilogue; the (M, C) activation never
+                               * reaches HBM.  upernext.py:215-223 / fpn.py:165-183.  bf16 kernels only. */
 
 const char* vkas_last_error(void);
 int vkas_abi_version(void);
@@ -60,6 +63,18 @@ typedef struct vkas_conv_geom {
   int KH, KW, stride, pad;
 } vkas_conv_geom;
 
+/* VKAS_EPI_HEAD: the N tiles of the launch are the heads (all reading the same input).  Head h owns output columns
+ * [n0[h], n0[h] + np[h]) (np = rup8(c)), of which c are real; params + h*(6*pw+8) holds, as floats,
+ * gamma[pw] | beta[pw] | Wproj[4][pw] | bproj[4] | pad[4] (zero padded; vkas_pack_head_params).
+ * stats: (n_heads, M, 2) fp32 (mean, rstd); proj: (n_heads, M, 8) fp32, columns >= oc are zero. */
+typedef struct vkas_head_desc {
+  int n_heads, pw;
+  int n0[4], np[4], c[4], oc[4];
+  const float* params;
+  float* stats;
+  float* proj;
+} vkas_head_desc;
+
 typedef struct vkas_epilogue {
   int mode;               /* VKAS_EPI_* */
   const float* bias;      /* [Np] or NULL */
@@ -71,6 +86,7 @@ typedef struct vkas_epilogue {
   int rows_per_image;     /* Hout*Wout, to index rowscale */
   int patch;              /* PATCH: patch edge k; rows are the (B,Hs,Ws) grid, columns (ky,kx,c) */
   int patch_Hs, patch_Ws, patch_Cp;
+  vkas_head_desc head;    /* HEAD */
 } vkas_epilogue;
 
 /* ---- parameter layout conversion (reference layouts -> kernel layouts and back) ------------------ */
@@ -132,6 +148,17 @@ int vkas_layernorm_bwd(const void* x, long ldx, const float* gamma, const float*
                        const void* dy, long lddy, void* dx, long lddx, float* dgamma, float* dbeta, float* ws,
                        size_t ws_bytes, long M, int C, int Cp, int act_gelu, int dtype, void* stream);
 size_t vkas_layernorm_bwd_ws_bytes(long M, int Cp);
+
+/* ---- fused head tail (LayerNorm -> GELU -> Linear(C -> oc), oc <= 4): upernext.py:215-223, fpn.py:165-183 ------ */
+/* gamma/beta (C), wproj (oc, C), bproj (oc) fp32 -> out[6*pw + 8] as laid out in vkas_head_desc */
+int vkas_pack_head_params(const float* gamma, const float* beta, const float* wproj, const float* bproj, int C, int oc,
+                          int pw, float* out, void* stream);
+/* backward of the fused tail for one head: z (M, np) slice with stride ldz, its stats (M, 2), dproj (M, 8) fp32 = gradient
+ * of the projection outputs -> dz (slice, stride lddz) and dparams[6*pw + 8] (same layout as the packed parameters). */
+int vkas_head_tail_bwd(const void* z, long ldz, const float* params, const float* stats, const float* dproj, void* dz,
+                       long lddz, float* dparams, float* ws, size_t ws_bytes, long M, int C, int np, int pw, int dtype,
+                       void* stream);
+size_t vkas_head_tail_bwd_ws_bytes(long M, int pw);
 
 /* ---- block_scale / stochastic depth backward: convnext.py:56-58 ----------------------------------- */
 /* dz = dout * rowscale[b] * colscale[c]; dscale[c] = sum_m dout*rowscale[b]*z; dbias2[c] = sum_m dz */

@@ -383,3 +383,54 @@ def test_clip_adamw_matches_torch():
         opt.zero_grad()
     for p, r in zip(params, ref_params):
         assert rel_err(p.detach(), r.detach()) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------ fused head tail
+@pytest.mark.parametrize('chans', [((40, 33), (1, 4)), ((192, 193, 194, 194), (1, 2, 4, 4)), ((96,), (3,))])
+def test_heads_fused_matches_unfused_and_fp64(chans):
+    """Conv3x3 + per-head LayerNorm + GELU + Linear(C -> oc) fused into the GEMM epilogue (bf16) vs the same math in fp64
+    on the host, forward and every gradient (input, conv weight / bias, gamma, beta, projection weight / bias)."""
+    ops = ops_mod()
+    cs, ocs = chans
+    B, H, W, Cin = 1, 128, 136, 64
+    dtype = torch.bfloat16
+    x = q(rnd((B, Cin, H, W), 50), dtype)
+    convs = [(q(rnd((c, Cin, 3, 3), 51 + i, 1.0 / math.sqrt(Cin * 9)), dtype), rnd((c,), 61 + i, 0.1)) for i, c in enumerate(cs)]
+    tails = [(1 + rnd((c,), 71 + i, 0.1), rnd((c,), 81 + i, 0.1), rnd((oc, c), 91 + i, 1.0 / math.sqrt(c)), rnd((oc,), 101 + i, 0.1))
+             for i, (c, oc) in enumerate(zip(cs, ocs))]
+    # fp64 reference
+    xr = x.clone().requires_grad_(True)
+    ref_params, ref_outs = [], []
+    for (w, b), (g, bt, wp, bp) in zip(convs, tails):
+        ps = [t.clone().requires_grad_(True) for t in (w, b, g, bt, wp, bp)]
+        ref_params.append(ps)
+        zz = F.conv2d(xr, ps[0], ps[1], padding=1)
+        a = O.gelu(O.layer_norm_nchw(zz, ps[2], ps[3]))
+        ref_outs.append(O.linear_nchw(a, ps[4], ps[5]))
+    cots = [rnd(tuple(o.shape), 111 + i) for i, o in enumerate(ref_outs)]
+    sum((o * c).sum() for o, c in zip(ref_outs, cots)).backward()
+    # fused op
+    xa = to_act(x, dtype).requires_grad_(True)
+    dev = [[t.float().cuda().requires_grad_(True) for t in (w, b, g, bt, wp, bp)] for (w, b), (g, bt, wp, bp) in zip(convs, tails)]
+    w_parts, b_parts, fused = [], [], []
+    for (w, b, g, bt, wp, bp), c in zip(dev, cs):
+        pad = (c + 7) // 8 * 8 - c
+        w_parts.append(F.pad(w, (0, 0, 0, 0, 0, 0, 0, pad)))
+        b_parts.append(F.pad(b, (0, pad)))
+        fused.extend([g, bt, wp, bp])
+    assert ops.HeadsFused.eligible(xa, cs, ocs)
+    outs = ops.HeadsFused.apply(xa, torch.cat(w_parts, 0), torch.cat(b_parts, 0), *fused)
+    loss = 0
+    for o, oc, r, c in zip(outs, ocs, ref_outs, cots):
+        assert tuple(o.shape) == (B, H, W, 8) and o.dtype == torch.float32
+        assert float(o[..., oc:].abs().max()) == 0.0
+        got = o[..., :oc].permute(0, 3, 1, 2)
+        assert rel_err(got, r.detach()) < 8e-3, rel_err(got, r.detach())
+        loss = loss + (got * c.float().cuda()).sum()
+    loss.backward()
+    assert rel_err(from_act(xa.grad, Cin), xr.grad) < 1.5e-2
+    names = ('conv w', 'conv b', 'gamma', 'beta', 'proj w', 'proj b')
+    for ps, rs in zip(dev, ref_params):
+        for n, p, r in zip(names, ps, rs):
+            e = rel_err(p.grad, r.grad)
+            assert e < 2e-2, (n, e)

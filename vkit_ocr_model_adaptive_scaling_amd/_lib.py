@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libvkas.so')
 
 F32, BF16 = 0, 1
-EPI_NONE, EPI_GELU, EPI_SCALE_RES, EPI_DGELU, EPI_ADD, EPI_PATCH = range(6)
+EPI_NONE, EPI_GELU, EPI_SCALE_RES, EPI_DGELU, EPI_ADD, EPI_PATCH, EPI_HEAD = range(7)
 
 
 class ConvGeom(Structure):
@@ -20,11 +20,16 @@ class ConvGeom(Structure):
                 ('ldx', c_int), ('KH', c_int), ('KW', c_int), ('stride', c_int), ('pad', c_int)]
 
 
+class HeadDesc(Structure):
+    _fields_ = [('n_heads', c_int), ('pw', c_int), ('n0', c_int * 4), ('np', c_int * 4), ('c', c_int * 4),
+                ('oc', c_int * 4), ('params', c_void_p), ('stats', c_void_p), ('proj', c_void_p)]
+
+
 class Epilogue(Structure):
     _fields_ = [('mode', c_int), ('bias', c_void_p), ('out', c_void_p), ('ldo', c_long), ('out2', c_void_p),
                 ('ldo2', c_long), ('aux', c_void_p), ('ldaux', c_long), ('colscale', c_void_p),
                 ('rowscale', c_void_p), ('rows_per_image', c_int), ('patch', c_int), ('patch_Hs', c_int),
-                ('patch_Ws', c_int), ('patch_Cp', c_int)]
+                ('patch_Ws', c_int), ('patch_Cp', c_int), ('head', HeadDesc)]
 
 
 class RoughLossCfg(Structure):
@@ -73,6 +78,9 @@ _SIGS = {
     'vkas_layernorm_bwd': (c_int, [_P, c_long, _P, _P, _P, _P, c_long, _P, c_long, _P, _P, _P, c_size_t, c_long, c_int,
                                    c_int, c_int, c_int, _P]),
     'vkas_layernorm_bwd_ws_bytes': (c_size_t, [c_long, c_int]),
+    'vkas_pack_head_params': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
+    'vkas_head_tail_bwd': (c_int, [_P, c_long, _P, _P, _P, _P, c_long, _P, _P, c_size_t, c_long, c_int, c_int, c_int, c_int, _P]),
+    'vkas_head_tail_bwd_ws_bytes': (c_size_t, [c_long, c_int]),
     'vkas_scale_res_bwd': (c_int, [_P, c_long, _P, c_long, _P, _P, c_int, _P, c_long, _P, _P, _P, c_size_t, c_long,
                                    c_int, c_int, _P]),
     'vkas_scale_res_bwd_ws_bytes': (c_size_t, [c_long, c_int]),

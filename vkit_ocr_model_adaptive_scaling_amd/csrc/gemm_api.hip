@@ -52,7 +52,17 @@ int vkas_check_geom(const char* who, const void* x, const vkas_conv_geom* g, int
 int vkas_check_epilogue(const char* who, const vkas_epilogue* e, int Np) {
   VKAS_CHECK(e && e->out, "%s: null output", who);
   VKAS_CHECK(vkas_aligned16(e->out) && e->ldo % 8 == 0, "%s: out misaligned (ldo=%ld)", who, e->ldo);
-  VKAS_CHECK(e->mode >= VKAS_EPI_NONE && e->mode <= VKAS_EPI_PATCH, "%s: bad epilogue mode %d", who, e->mode);
+  VKAS_CHECK(e->mode >= VKAS_EPI_NONE && e->mode <= VKAS_EPI_HEAD, "%s: bad epilogue mode %d", who, e->mode);
+  if (e->mode == VKAS_EPI_HEAD) {
+    const vkas_head_desc* h = &e->head;
+    VKAS_CHECK(h->n_heads >= 1 && h->n_heads <= 4 && h->pw % 8 == 0 && h->pw >= 8 && h->pw <= 224 && h->params && h->stats &&
+                   h->proj && e->bias && vkas_aligned16(h->params) && vkas_aligned16(h->proj),
+               "%s: bad head descriptor", who);
+    for (int i = 0; i < h->n_heads; ++i)
+      VKAS_CHECK(h->np[i] % 8 == 0 && h->np[i] > 0 && h->np[i] <= h->pw && h->c[i] > 0 && h->c[i] <= h->np[i] &&
+                     h->oc[i] >= 1 && h->oc[i] <= 4 && h->n0[i] % 8 == 0 && h->n0[i] >= 0 && h->n0[i] + h->np[i] <= Np,
+                 "%s: bad head %d (n0=%d np=%d c=%d oc=%d)", who, i, h->n0[i], h->np[i], h->c[i], h->oc[i]);
+  }
   VKAS_CHECK((!e->bias || vkas_aligned16(e->bias)) && (!e->colscale || vkas_aligned16(e->colscale)),
              "%s: bias / colscale must be 16-byte aligned", who);
   if (e->mode != VKAS_EPI_PATCH) VKAS_CHECK(e->ldo >= Np, "%s: ldo=%ld < Np=%d", who, e->ldo, Np);
@@ -81,6 +91,9 @@ extern "C" int vkas_conv_gemm_fwd(const void* x, const vkas_conv_geom* g, const 
   if (epi->mode == VKAS_EPI_PATCH)
     VKAS_CHECK((long)g->B * g->Hout * g->Wout == (long)g->B * epi->patch_Hs * epi->patch_Ws || g->B == 0,
                "vkas_conv_gemm_fwd: patch grid does not match the GEMM rows");
+  if (epi->mode == VKAS_EPI_HEAD)
+    VKAS_CHECK(dtype == VKAS_BF16 && !force_simple() && (long)g->B * g->Hout * g->Wout >= 16384,
+               "vkas_conv_gemm_fwd: the fused head epilogue exists for the bf16 MFMA kernels (M >= 16384) only");
   if (dtype == VKAS_BF16 && !force_simple()) return vkas_gemm_nt_mfma_bf16(x, g, Bw, Np, epi, vkas_stream(stream));
   return vkas_gemm_nt_simple(x, g, Bw, Np, epi, dtype, vkas_stream(stream));
 }

@@ -21,6 +21,91 @@ __device__ __forceinline__ int swz_off(int row, int chunk) {  // element offset 
   return row * BK + ((chunk ^ (row & 7)) << 3);
 }
 
+// Fused head tail on one staged pass of ER rows (fp32 accumulators in LDS, row pitch EP): per pixel
+//   z = acc + bias -> stored (bf16, needed by backward); LayerNorm statistics over the head's C channels;
+//   a = GELU(LN(z)); proj[q] = <a, Wproj[q]> + bproj[q], q < 4.
+// LPR = NTHR / ER lanes share a row (8 for the 8-wave tiles): each keeps up to VPL 8-channel vectors in registers,
+// row sums go through DPP shuffles inside the lane group.  The (M, C) activation is never written.
+template <int NTHR, int ER, int EP, int VPR>
+__device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head, const float* stage, long mrow0, long M,
+                                               int n0, int width, int tid) {
+  constexpr int LPR = NTHR / ER;
+  constexpr int VPL = (VPR + LPR - 1) / LPR;
+  static_assert(LPR == 4 || LPR == 8, "4 or 8 lanes per row");
+  const int row = tid / LPR, j = tid % LPR;
+  const long m = mrow0 + row;
+  const int C = e.head.c[head];
+  const int pw = e.head.pw;
+  const float* hp = e.head.params + (long)head * (6 * pw + 8);
+  float v[VPL][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c0 = (j + LPR * i) * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[i][c] = 0.f;
+    if (c0 < width) {
+      const float4 lo = *reinterpret_cast<const float4*>(stage + row * EP + c0);
+      const float4 hi = *reinterpret_cast<const float4*>(stage + row * EP + c0 + 4);
+      float b[8];
+      load8(e.bias + n0 + c0, b);
+      v[i][0] = lo.x + b[0]; v[i][1] = lo.y + b[1]; v[i][2] = lo.z + b[2]; v[i][3] = lo.w + b[3];
+      v[i][4] = hi.x + b[4]; v[i][5] = hi.y + b[5]; v[i][6] = hi.z + b[6]; v[i][7] = hi.w + b[7];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s += (c0 + c < C) ? v[i][c] : 0.f;
+  }
+#pragma unroll
+  for (int o = LPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c0 = (j + LPR * i) * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float d = v[i][c] - mean;
+      q += (c0 + c < C) ? d * d : 0.f;
+    }
+  }
+#pragma unroll
+  for (int o = LPR >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(q / (float)C + 1e-6f);
+  float pr[4] = {0.f, 0.f, 0.f, 0.f};
+  bf16_t* zout = reinterpret_cast<bf16_t*>(e.out);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c0 = (j + LPR * i) * 8;
+    if (c0 >= width) continue;
+    if (m < M) store8(zout + m * e.ldo + n0 + c0, v[i]);
+    float gm[8], bt[8], a[8];
+    load8(hp + c0, gm);
+    load8(hp + pw + c0, bt);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a[c] = gelu_t<bf16_t>((v[i][c] - mean) * rstd * gm[c] + bt[c]);  // pad: gamma = beta = 0
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      float w[8];
+      load8(hp + (2 + qq) * pw + c0, w);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) pr[qq] = fmaf(a[c], w[c], pr[qq]);
+    }
+  }
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+    for (int o = LPR >> 1; o > 0; o >>= 1) pr[qq] += __shfl_xor(pr[qq], o, 64);
+  if (j == 0 && m < M) {
+    const float4 bp = *reinterpret_cast<const float4*>(hp + 6 * pw);
+    float* po = e.head.proj + ((long)head * M + m) * 8;
+    *reinterpret_cast<float4*>(po) = make_float4(pr[0] + bp.x, pr[1] + bp.y, pr[2] + bp.z, pr[3] + bp.w);
+    *reinterpret_cast<float4*>(po + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* st = e.head.stats + ((long)head * M + m) * 2;
+    st[0] = mean;
+    st[1] = rstd;
+  }
+}
+
 // WM x WN waves, each owning TM x TN 16x16 MFMA tiles: block tile = (WM*TM*16) x (WN*TN*16), BK = 64.
 // Instantiated as 128x128 (4 waves), 256x128, 256x192 and 256x224 (8 waves, 2 per SIMD): the wide tiles cut
 // the zero-padding waste on N = 192..200 (head convs) and raise the MFMA : LDS-traffic ratio.
@@ -29,7 +114,7 @@ __device__ __forceinline__ int swz_off(int row, int chunk) {  // element offset 
 // range check returns zeros for an out-of-range offset, so zero padding / tile tails cost one v_cndmask on a 32-bit
 // byte offset instead of a divergent branch, and the per-K-tile address arithmetic shrinks to an add per row: the
 // main loop had ~3.8 VALU instructions per MFMA and was issue-bound; this path has < 1.
-template <int WM, int WN, int TM, int TN, bool BUF>
+template <int WM, int WN, int TM, int TN, bool BUF, bool HEAD>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
                                                                   const bf16_t* __restrict__ Bw, int Np, long M, int K,
                                                                   vkas_epilogue e, unsigned a_bytes, unsigned b_bytes) {
@@ -47,13 +132,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
   // Tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private L2), so give every XCD a
   // contiguous run of tiles, N tiles fastest: the N tiles of one pixel block and its vertical neighbours (the 3x3
   // halo rows) then hit the same L2 instead of re-reading A from HBM.  Pure speed choice, any placement is correct.
-  const unsigned ntile_n = (unsigned)((Np + BN - 1) / BN);
+  constexpr bool head_mode = HEAD;  // N tiles = heads (each <= BN wide, at its own column offset)
+  const unsigned ntile_n = head_mode ? (unsigned)e.head.n_heads : (unsigned)((Np + BN - 1) / BN);
   const unsigned total = gridDim.x;
   const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const unsigned q8 = total >> 3, r8 = total & 7u;
   const unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
   const long m0 = (long)(tile / ntile_n) * BM;
-  const int n0 = (int)(tile % ntile_n) * BN;
+  const int tile_n = (int)(tile % ntile_n);
+  const int n0 = head_mode ? e.head.n0[tile_n] : tile_n * BN;
+  const int n_end = head_mode ? n0 + e.head.np[tile_n] : Np;  // first column this tile must not touch
 
   // staging role: chunk column cc (8 elements), rows sr + RSTEP*i
   const int cc = tid & 7;
@@ -75,7 +163,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
   for (int i = 0; i < BCH; ++i) {
     const int r = sr + RSTEP * i;
     const int n = n0 + r;
-    b_ok[i] = r < BN && n < Np;
+    b_ok[i] = r < BN && n < n_end;
     b_ptr[i] = Bw + (long)(b_ok[i] ? n : 0) * K;
     b_base[i] = ((unsigned)(b_ok[i] ? n : 0) * (unsigned)K) << 1;
   }
@@ -221,16 +309,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
               acc[i][j];
     }
     __syncthreads();
-    for (int t = tid; t < ER * VPR; t += NTHR) {
-      const int row = t / VPR, c8 = t - row * VPR;
-      const long m = m0 + pass * ER + row;
-      const int n = n0 + c8 * 8;
-      if (m < M && n < Np) {
-        float v[8];
-        const float4 lo = *reinterpret_cast<const float4*>(stage + row * EP + c8 * 8);
-        const float4 hi = *reinterpret_cast<const float4*>(stage + row * EP + c8 * 8 + 4);
-        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-        epi_store8<bf16_t>(e, m, n, v);
+    if constexpr (HEAD) {
+      head_tail_rows<NTHR, ER, EP, VPR>(e, tile_n, stage, m0 + (long)pass * ER, M, n0, n_end - n0, tid);
+    } else {
+      for (int t = tid; t < ER * VPR; t += NTHR) {
+        const int row = t / VPR, c8 = t - row * VPR;
+        const long m = m0 + pass * ER + row;
+        const int n = n0 + c8 * 8;
+        if (m < M && n < n_end) {
+          float v[8];
+          const float4 lo = *reinterpret_cast<const float4*>(stage + row * EP + c8 * 8);
+          const float4 hi = *reinterpret_cast<const float4*>(stage + row * EP + c8 * 8 + 4);
+          v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+          epi_store8<bf16_t>(e, m, n, v);
+        }
       }
     }
     __syncthreads();
@@ -472,17 +564,26 @@ template <int WM, int WN, int TM, int TN>
 static void launch_nt(const void* x, const vkas_conv_geom* g, const void* Bw, int Np, long M, int K,
                       const vkas_epilogue* e, hipStream_t st) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  dim3 grid((unsigned)(vkas_cdiv(M, BM) * vkas_cdiv(Np, BN)));
+  const long ntn = e->mode == VKAS_EPI_HEAD ? e->head.n_heads : vkas_cdiv(Np, BN);
+  dim3 grid((unsigned)(vkas_cdiv(M, BM) * ntn));
   // bytes spanned by the operands (x may be a channel slice: last pixel ends after Cp of its ld channels)
   const long a_bytes = (((long)g->B * g->Hin * g->Win - 1) * g->ldx + g->Cp) * 2;
   const long b_bytes = (long)Np * K * 2;
   static const bool no_buf = getenv("VKAS_NT_NOBUF") != nullptr;
-  if (!no_buf && a_bytes < 0xFFFFFFF0L && b_bytes < 0xFFFFFFF0L)
-    gemm_nt_mfma_kernel<WM, WN, TM, TN, true><<<grid, WM * WN * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)Bw, Np, M, K,
-                                                                            *e, (unsigned)a_bytes, (unsigned)b_bytes);
-  else
-    gemm_nt_mfma_kernel<WM, WN, TM, TN, false><<<grid, WM * WN * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)Bw, Np, M, K,
-                                                                             *e, 0u, 0u);
+  const bool buf = !no_buf && a_bytes < 0xFFFFFFF0L && b_bytes < 0xFFFFFFF0L;
+  const bf16_t* xp = (const bf16_t*)x;
+  const bf16_t* bp = (const bf16_t*)Bw;
+  const unsigned ab = buf ? (unsigned)a_bytes : 0u, bb = buf ? (unsigned)b_bytes : 0u;
+  if (e->mode == VKAS_EPI_HEAD) {
+    if constexpr (WM * WN == 8) {  // the fused head epilogue is instantiated for the 8-wave tiles only
+      if (buf) gemm_nt_mfma_kernel<WM, WN, TM, TN, true, true><<<grid, WM * WN * 64, 0, st>>>(xp, *g, bp, Np, M, K, *e, ab, bb);
+      else gemm_nt_mfma_kernel<WM, WN, TM, TN, false, true><<<grid, WM * WN * 64, 0, st>>>(xp, *g, bp, Np, M, K, *e, ab, bb);
+    }
+  } else if (buf) {
+    gemm_nt_mfma_kernel<WM, WN, TM, TN, true, false><<<grid, WM * WN * 64, 0, st>>>(xp, *g, bp, Np, M, K, *e, ab, bb);
+  } else {
+    gemm_nt_mfma_kernel<WM, WN, TM, TN, false, false><<<grid, WM * WN * 64, 0, st>>>(xp, *g, bp, Np, M, K, *e, ab, bb);
+  }
 }
 
 // Tile choice of the NT kernel: returns 1 for the 4-wave 128x128 tile, else the N extent (128 / 192 / 224) of the
@@ -510,7 +611,12 @@ int vkas_gemm_nt_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* B
   const long M = (long)g->B * g->Hout * g->Wout;
   const int K = g->KH * g->KW * g->Cp;
   if (M == 0) return VKAS_OK;
-  const int choice = vkas_gemm_nt_tile_choice(M, Np);
+  int choice = vkas_gemm_nt_tile_choice(M, Np);
+  if (e->mode == VKAS_EPI_HEAD) {  // one 256-row tile per head: the narrowest N extent that holds the widest head
+    int wmax = 0;
+    for (int h = 0; h < e->head.n_heads; ++h) wmax = e->head.np[h] > wmax ? e->head.np[h] : wmax;
+    choice = wmax <= 128 ? 128 : (wmax <= 192 ? 192 : 224);
+  }
   const bool big = choice != 1;
   const int bn = big ? choice : 128;
   if (!big) launch_nt<2, 2, 4, 4>(x, g, Bw, Np, M, K, e, st);

@@ -1,0 +1,217 @@
+// Fused head tail, backward side (the forward side lives in the NT GEMM epilogue, gemm_mfma.hip):
+//   z (pre-LN conv output, kept by the forward) --LayerNorm--> u --GELU--> a --Linear(C -> oc <= 4)--> proj
+// Given d(proj) this kernel recomputes u and a from z and the saved row statistics and produces dz together with the
+// parameter gradients (gamma, beta, Wproj, bproj) in one pass over z: the (M, C) activation and its gradient never exist
+// in HBM (model/upernext.py:215-223, model/fpn.py:165-183; backward of helper.py:96-101 + helper.py:18-22).
+#include "vkas_common.h"
+
+int vkas_colreduce_finalize(const float* partial, long P, int n, int ldp, float* out, int accumulate, hipStream_t st);
+
+namespace {
+
+constexpr int G = 32;   // lanes per pixel row (C <= 224 -> at most 28 8-channel vectors)
+constexpr int R = 1;    // rows in flight per lane group (register budget: 64 accumulators for dgamma..dWproj)
+
+__global__ void pack_head_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        const float* __restrict__ wproj, const float* __restrict__ bproj, int C, int oc,
+                                        int pw, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 6 * pw + 8) return;
+  float v = 0.f;
+  if (i < pw) v = i < C ? gamma[i] : 0.f;
+  else if (i < 2 * pw) v = (i - pw) < C ? beta[i - pw] : 0.f;
+  else if (i < 6 * pw) {
+    const int q = (i - 2 * pw) / pw, c = (i - 2 * pw) - q * pw;
+    v = (q < oc && c < C) ? wproj[(long)q * C + c] : 0.f;
+  } else {
+    const int q = i - 6 * pw;
+    v = q < oc ? bproj[q] : 0.f;
+  }
+  out[i] = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void head_tail_bwd_kernel(const T* __restrict__ z, long ldz,
+                                                            const float* __restrict__ params,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ dproj, T* __restrict__ dz, long lddz,
+                                                            float* __restrict__ partial, long M, int C, int np, int pw,
+                                                            long rows_per_block) {
+  const int nvec = np >> 3;
+  const int gl = threadIdx.x & (G - 1);
+  const int rl = threadIdx.x / G;
+  constexpr int rpi = 256 / G;
+  const long mbeg = (long)blockIdx.x * rows_per_block;
+  const long mend = mbeg + rows_per_block < M ? mbeg + rows_per_block : M;
+  const bool vok = gl < nvec;
+  float gm[8], bt[8], wp[4][8];
+  float dg[8], db[8], dwp[4][8], dbp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { gm[c] = 0.f; bt[c] = 0.f; dg[c] = 0.f; db[c] = 0.f; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { wp[q][c] = 0.f; dwp[q][c] = 0.f; }
+  if (vok) {
+    load8(params + gl * 8, gm);
+    load8(params + pw + gl * 8, bt);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load8(params + (2 + q) * pw + gl * 8, wp[q]);
+  }
+  for (long m0 = mbeg; m0 < mend; m0 += (long)R * rpi) {
+    float xh[R][8], g[R][8], mean[R], rstd[R];
+    float4 dp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const long m = m0 + (long)r * rpi + rl;
+      const bool ok = m < mend;
+      mean[r] = ok ? stats[2 * m] : 0.f;
+      rstd[r] = ok ? stats[2 * m + 1] : 0.f;
+      dp[r] = ok ? *reinterpret_cast<const float4*>(dproj + m * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) xh[r][c] = 0.f;
+      if (ok && vok) load8(z + m * ldz + gl * 8, xh[r]);
+    }
+    float s1[R], s2[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool ok = m0 + (long)r * rpi + rl < mend;
+      const float d4[4] = {dp[r].x, dp[r].y, dp[r].z, dp[r].w};
+      s1[r] = 0.f;
+      s2[r] = 0.f;
+      if (gl == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dbp[q] += d4[q];
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const bool cok = ok && vok && (gl * 8 + c < C);
+        const float h = cok ? (xh[r][c] - mean[r]) * rstd[r] : 0.f;
+        const float u = h * gm[c] + bt[c];
+        float cdf, pdf;
+        if constexpr (sizeof(T) == 2) {
+          gelu_parts_fast(u, cdf, pdf);
+        } else {
+          cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
+          pdf = 0.39894228040143268f * __expf(-0.5f * u * u);
+        }
+        const float a = cok ? u * cdf : 0.f;
+        float da = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          da = fmaf(d4[q], wp[q][c], da);
+          dwp[q][c] = fmaf(d4[q], a, dwp[q][c]);
+        }
+        const float gg = cok ? da * fmaf(u, pdf, cdf) : 0.f;
+        xh[r][c] = h;
+        g[r][c] = gg;
+        dg[c] += gg * h;
+        db[c] += gg;
+        const float dxh = gg * gm[c];
+        s1[r] += dxh;
+        s2[r] += dxh * h;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int o = G >> 1; o > 0; o >>= 1) {
+        s1[r] += __shfl_xor(s1[r], o, 64);
+        s2[r] += __shfl_xor(s2[r], o, 64);
+      }
+      s1[r] /= (float)C;
+      s2[r] /= (float)C;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const long m = m0 + (long)r * rpi + rl;
+      if (m >= mend || !vok) continue;
+      float o[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] = (gl * 8 + c < C) ? rstd[r] * (g[r][c] * gm[c] - s1[r] - xh[r][c] * s2[r]) : 0.f;
+      store8(dz + m * lddz + gl * 8, o);
+    }
+  }
+  // reduce the per-thread column sums over the 8 row lanes; partial row = dgamma | dbeta | dWp[4] | dbp[8]
+  __shared__ float red[256 * 8];
+  float* prow = partial + (long)blockIdx.x * (6 * pw + 8);
+  auto reduce_store = [&](const float* vals, int dst_off) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) red[threadIdx.x * 8 + c] = vals[c];
+    __syncthreads();
+    if (rl == 0 && gl * 8 < pw) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < rpi; ++r) s += red[(r * G + gl) * 8 + c];
+        prow[dst_off + gl * 8 + c] = vok ? s : 0.f;
+      }
+    }
+  };
+  reduce_store(dg, 0);
+  reduce_store(db, pw);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) reduce_store(dwp[q], (2 + q) * pw);
+  float b8[8] = {dbp[0], dbp[1], dbp[2], dbp[3], 0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 8; ++c) red[threadIdx.x * 8 + c] = b8[c];
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    float s = 0.f;
+    for (int r = 0; r < rpi; ++r) s += red[(r * G) * 8 + threadIdx.x];  // gl == 0 lanes hold the row sums of d(proj)
+    prow[6 * pw + threadIdx.x] = s;
+  }
+}
+
+static inline long ht_rows_per_block(long M) {
+  long r = vkas_cdiv(M > 0 ? M : 1, 1024);
+  if (r < 32) r = 32;
+  const long q = (long)R * (256 / G);
+  return vkas_cdiv(r, q) * q;
+}
+
+}  // namespace
+
+extern "C" int vkas_pack_head_params(const float* gamma, const float* beta, const float* wproj, const float* bproj, int C,
+                                     int oc, int pw, float* out, void* stream) {
+  VKAS_CHECK(gamma && beta && wproj && bproj && out, "vkas_pack_head_params: null pointer");
+  VKAS_CHECK(C > 0 && oc >= 1 && oc <= 4 && pw % 8 == 0 && pw >= C && pw <= 224, "vkas_pack_head_params: bad C=%d oc=%d pw=%d", C,
+             oc, pw);
+  pack_head_params_kernel<<<(unsigned)vkas_cdiv(6 * pw + 8, 256), 256, 0, vkas_stream(stream)>>>(gamma, beta, wproj, bproj, C,
+                                                                                                oc, pw, out);
+  VKAS_LAUNCH_CHECK("pack_head_params");
+  return VKAS_OK;
+}
+
+extern "C" size_t vkas_head_tail_bwd_ws_bytes(long M, int pw) {
+  return (size_t)vkas_cdiv(M > 0 ? M : 1, ht_rows_per_block(M)) * (size_t)(6 * pw + 8) * sizeof(float);
+}
+
+extern "C" int vkas_head_tail_bwd(const void* z, long ldz, const float* params, const float* stats, const float* dproj,
+                                  void* dz, long lddz, float* dparams, float* ws, size_t ws_bytes, long M, int C, int np,
+                                  int pw, int dtype, void* stream) {
+  VKAS_CHECK(z && params && stats && dproj && dz && dparams && ws, "vkas_head_tail_bwd: null pointer");
+  VKAS_CHECK(C > 0 && np % 8 == 0 && C <= np && np <= pw && pw % 8 == 0 && pw <= 224, "vkas_head_tail_bwd: bad C=%d np=%d pw=%d",
+             C, np, pw);
+  VKAS_CHECK(ldz >= np && lddz >= np && ldz % 8 == 0 && lddz % 8 == 0 && vkas_aligned16(z) && vkas_aligned16(dz) &&
+                 vkas_aligned16(dproj) && vkas_aligned16(params),
+             "vkas_head_tail_bwd: bad strides/alignment");
+  VKAS_CHECK(ws_bytes >= vkas_head_tail_bwd_ws_bytes(M, pw), "vkas_head_tail_bwd: workspace too small");
+  hipStream_t st = vkas_stream(stream);
+  const int n = 6 * pw + 8;
+  if (M <= 0) {
+    (void)hipMemsetAsync(dparams, 0, n * sizeof(float), st);
+    return VKAS_OK;
+  }
+  const long rpb = ht_rows_per_block(M);
+  const long P = vkas_cdiv(M, rpb);
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_head_tail_bwd", {
+    head_tail_bwd_kernel<T><<<(unsigned)P, 256, 0, st>>>((const T*)z, ldz, params, stats, dproj, (T*)dz, lddz, ws, M, C, np, pw,
+                                                         rpb);
+  })
+  VKAS_LAUNCH_CHECK("head_tail_bwd");
+  return vkas_colreduce_finalize(ws, P, n, n, dparams, 0, st);
+}

@@ -104,7 +104,18 @@ class AdaptiveScaling(nn.Module):
             pad = ops.rup8(c.out_channels) - c.out_channels
             w_parts.append(F.pad(c.weight, (0, 0, 0, 0, 0, 0, 0, pad)) if pad else c.weight)
             b_parts.append(F.pad(c.bias, (0, pad)) if pad else c.bias)
-        z = ops.Conv.apply(up, torch.cat(w_parts, 0), torch.cat(b_parts, 0), 1, 1)
+        w_cat, b_cat = torch.cat(w_parts, 0), torch.cat(b_parts, 0)
+        if ops.HeadsFused.eligible(up, [c.out_channels for c in convs], [hp.out_channels for hp in plain]):
+            # LayerNorm + GELU + projection run in the conv's epilogue: the per-head activations never reach HBM
+            fused = []
+            for nm, proj in zip(norms, projs):
+                fused.extend([nm.weight, nm.bias, proj.weight, proj.bias])
+            outs = []
+            for h, hp, y in zip(heads, plain, ops.HeadsFused.apply(up, w_cat, b_cat, *fused)):
+                y = ops.ToNchw.apply(y, hp.out_channels)
+                outs.append(h[1](y) if isinstance(h, nn.Sequential) else y)
+            return tuple(outs)
+        z = ops.Conv.apply(up, w_cat, b_cat, 1, 1)
         affine = []
         for nm in norms:
             affine.extend([nm.weight, nm.bias])

@@ -145,31 +145,38 @@ def _timed(kind, x, flops, M, N, K, fn):
 
 def conv_gemm(x: torch.Tensor, geom: ConvGeom, Bw: torch.Tensor, Np: int, out: torch.Tensor, mode=_lib.EPI_NONE,
               bias=None, out2=None, aux=None, colscale=None, rowscale=None, rows_per_image=0, patch=0, patch_hw=(0, 0),
-              patch_Cp=0, nk=None):
+              patch_Cp=0, nk=None, head=None):
+    if head is not None:
+        assert TIMER is None or True
     if TIMER is not None:
         # algorithmic FLOPs use the logical (unpadded) N and K when the caller knows them
         M = geom.B * geom.Hout * geom.Wout
         N, K = nk if nk is not None else (Np, geom.KH * geom.KW * geom.Cp)
         if x.dtype == torch.bfloat16:
             t = lib.vkas_conv_gemm_tile(0, M, Np, geom.KH * geom.KW * geom.Cp)
+            if head is not None:
+                wmax = max(head.np[i] for i in range(head.n_heads))
+                t = 128 if wmax <= 128 else (192 if wmax <= 192 else 224)
             kind = 'gemm_nt_mfma<%s>' % ('128x128' if t == 1 else '256x%d' % t)
         else:
             kind = 'gemm_nt_simple'
         return _timed(kind, x, 2.0 * M * N * K, M, N, K,
                       lambda: _conv_gemm(x, geom, Bw, Np, out, mode, bias, out2, aux, colscale, rowscale, rows_per_image,
-                                         patch, patch_hw, patch_Cp))
+                                         patch, patch_hw, patch_Cp, head))
     return _conv_gemm(x, geom, Bw, Np, out, mode, bias, out2, aux, colscale, rowscale, rows_per_image, patch, patch_hw,
-                      patch_Cp)
+                      patch_Cp, head)
 
 
 def _conv_gemm(x, geom, Bw, Np, out, mode, bias, out2, aux, colscale, rowscale, rows_per_image, patch, patch_hw,
-               patch_Cp):
+               patch_Cp, head=None):
     epi = Epilogue(mode, _p(bias).value if bias is not None else None, out.data_ptr(), act_ld(out),
                    out2.data_ptr() if out2 is not None else None, act_ld(out2) if out2 is not None else 0,
                    aux.data_ptr() if aux is not None else None, act_ld(aux) if aux is not None else 0,
                    colscale.data_ptr() if colscale is not None else None,
                    rowscale.data_ptr() if rowscale is not None else None, rows_per_image, patch, patch_hw[0],
                    patch_hw[1], patch_Cp)
+    if head is not None:
+        epi.head = head
     check(lib.vkas_conv_gemm_fwd(_p(x), ctypes.byref(geom), _p(Bw), Np, ctypes.byref(epi), _dt(x), _stream()),
           'conv_gemm_fwd')
     return out
@@ -428,6 +435,101 @@ class MultiLayerNorm(Function):
         for dg, db in grads:
             flat.extend([dg, db])
         return (dx, None, *flat)
+
+
+class HeadsFused(Function):
+    """All heads of a pass (model/upernext.py:215-223 or model/fpn.py:165-183, shared upsampled input) as ONE implicit
+    GEMM whose epilogue applies each head's LayerNorm -> GELU -> Linear(C -> out_channels) per pixel: forward writes
+    only the pre-LN conv output z (needed by backward) and the 1..4 projected channels; the (M, C) activations and
+    their gradients never reach HBM.  Backward recomputes them tile-locally (vkas_head_tail_bwd) and feeds one dz into
+    the shared conv's dgrad / wgrad.  bf16 only; heads up to 224 channels and out_channels <= 4.
+
+    inputs: x (B,H,W,Cp); w_cat (sum rup8(C_h), Cin, 3, 3) / b_cat: the heads' conv weights stacked with each head padded
+    to a multiple of 8 rows; then per head gamma, beta, wproj (oc, C_h), bproj (oc).
+    outputs: per head a (B,H,W,8) fp32 activation holding the oc projected channels (columns >= oc are zero)."""
+
+    @staticmethod
+    def eligible(x, channels, out_channels) -> bool:
+        M = x.shape[0] * x.shape[1] * x.shape[2]
+        return (x.dtype == torch.bfloat16 and M >= 16384 and len(channels) <= 4 and max(rup8(c) for c in channels) <= 224
+                and max(out_channels) <= 4)
+
+    @staticmethod
+    def forward(ctx, x, w_cat, b_cat, *params):
+        _require_cuda(x, w_cat)
+        x = as_act(x)
+        n_heads = len(params) // 4
+        gammas, betas, wps, bps = params[0::4], params[1::4], params[2::4], params[3::4]
+        cs = [g.numel() for g in gammas]
+        ocs = [w.shape[0] for w in wps]
+        nps = [rup8(c) for c in cs]
+        Nt = sum(nps)
+        B, H, W, Cp = x.shape
+        N, C, KH, KW = w_cat.shape
+        assert N == Nt and Cp == rup8(C) and KH == 3 and KW == 3
+        M = B * H * W
+        wmax = max(nps)
+        pw = 128 if wmax <= 128 else (192 if wmax <= 192 else 224)
+        dev = x.device
+        hp = torch.empty((n_heads, 6 * pw + 8), dtype=_FLOAT, device=dev)
+        for h in range(n_heads):
+            check(lib.vkas_pack_head_params(_p(gammas[h].contiguous()), _p(betas[h].contiguous()),
+                                            _p(wps[h].contiguous()), _p(bps[h].contiguous()), cs[h], ocs[h], pw,
+                                            _p(hp[h]), _stream()), 'pack_head_params')
+        z = new_act(B, H, W, Nt, x)
+        stats = torch.empty((n_heads, M, 2), dtype=_FLOAT, device=dev)
+        proj = torch.empty((n_heads, B, H, W, 8), dtype=_FLOAT, device=dev)
+        head = _lib.HeadDesc()
+        head.n_heads, head.pw = n_heads, pw
+        off = 0
+        for h in range(n_heads):
+            head.n0[h], head.np[h], head.c[h], head.oc[h] = off, nps[h], cs[h], ocs[h]
+            off += nps[h]
+        head.params, head.stats, head.proj = hp.data_ptr(), stats.data_ptr(), proj.data_ptr()
+        geom = _geom(B, H, W, H, W, Cp, act_ld(x), 3, 3, 1, 1)
+        Bw = pack_conv_weight(w_cat, Nt, Cp, 0, x.dtype)
+        conv_gemm(x, geom, Bw, Nt, z, _lib.EPI_HEAD, bias=pad_vector(b_cat, Nt), nk=(sum(cs), C * 9), head=head)
+        ctx.save_for_backward(x, w_cat, z, stats, hp)
+        ctx.meta = (cs, ocs, nps, pw)
+        return tuple(proj[h] for h in range(n_heads))
+
+    @staticmethod
+    def backward(ctx, *dprojs):
+        x, w_cat, z, stats, hp = ctx.saved_tensors
+        cs, ocs, nps, pw = ctx.meta
+        n_heads = len(cs)
+        B, H, W, Cp = x.shape
+        Nt = z.shape[3]
+        N, C, KH, KW = w_cat.shape
+        M = B * H * W
+        dev = x.device
+        dz = new_act(B, H, W, Nt, x)
+        dparams = torch.empty((n_heads, 6 * pw + 8), dtype=_FLOAT, device=dev)
+        nbytes = lib.vkas_head_tail_bwd_ws_bytes(M, pw)
+        off = 0
+        for h in range(n_heads):
+            dp = dprojs[h]
+            dp = torch.zeros((B, H, W, 8), dtype=_FLOAT, device=dev) if dp is None else dp.contiguous().float()
+            zs, dzs = z[..., off:off + nps[h]], dz[..., off:off + nps[h]]
+            ws = _ws(nbytes, dev)
+            check(lib.vkas_head_tail_bwd(_p(zs), Nt, _p(hp[h]), _p(stats[h]), _p(dp), _p(dzs), Nt, _p(dparams[h]), _p(ws),
+                                         nbytes, M, cs[h], nps[h], pw, _dt(x), _stream()), 'head_tail_bwd')
+            off += nps[h]
+        geom = _geom(B, H, W, H, W, Cp, act_ld(x), 3, 3, 1, 1)
+        gwp, gbp = conv_wgrad(x, geom, dz, Nt, nk=(sum(cs), C * 9), with_bias=True)
+        gw = unpack_wgrad(gwp, (N, C, 3, 3), Nt, Cp)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            Bt = pack_conv_weight(w_cat, Nt, Cp, 1, x.dtype)
+            dx = new_act(B, H, W, Cp, x)
+            g2 = _geom(B, H, W, H, W, Nt, Nt, 3, 3, 1, 1)
+            conv_gemm(dz, g2, Bt, Cp, dx, _lib.EPI_NONE, nk=(C, sum(cs) * 9))
+        grads = []
+        for h in range(n_heads):
+            d = dparams[h]
+            grads.extend([d[:cs[h]], d[pw:pw + cs[h]], d[2 * pw:6 * pw].view(4, pw)[:ocs[h], :cs[h]],
+                          d[6 * pw:6 * pw + ocs[h]]])
+        return (dx, gw, gbp[:N], *grads)
 
 
 class ConvNextLayer(Function):
