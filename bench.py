@@ -176,15 +176,24 @@ def main():
         summ = timer.summary()
         if args.detail:
             shapes = {}
-            for kind, s_, e_, flops, M, N, K in timer.records:
-                d_ = shapes.setdefault((kind, M, N, K), [0, 0.0, 0.0])
+            for kind, s_, e_, flops, M, N, K, nb_ in timer.records:
+                d_ = shapes.setdefault((kind, M, N, K), [0, 0.0, 0.0, 0.0])
                 d_[0] += 1
                 d_[1] += s_.elapsed_time(e_)
                 d_[2] += flops
-            print('[bench] kind M N K launches/step ms/step TFLOP/s', file=sys.stderr)
-            for key, (n_, ms_, fl_) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
-                print(f'[bench] {key[0]:14s} {key[1]:8d} {key[2]:5d} {key[3]:5d} {n_ / args.steps:6.1f} '
-                      f'{ms_ / args.steps:8.3f} {fl_ / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0:8.1f}', file=sys.stderr)
+                d_[3] += nb_
+            # roof ms/step = max(flops / dense bf16 MFMA peak, algorithmic bytes / HBM peak)
+            print('[bench] kind M N K launches/step ms/step TFLOP/s TB/s roof_ms/step', file=sys.stderr)
+            tot_ms = tot_roof = 0.0
+            for key, (n_, ms_, fl_, nb_) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                roof_ = max(fl_ / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12), nb_ / 8e12) * 1e3
+                tot_ms += ms_
+                tot_roof += roof_
+                print(f'[bench] {key[0]:22s} {key[1]:8d} {key[2]:5d} {key[3]:5d} {n_ / args.steps:6.1f} '
+                      f'{ms_ / args.steps:8.3f} {fl_ / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0:8.1f} '
+                      f'{nb_ / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0:6.2f} {roof_ / args.steps:8.3f}', file=sys.stderr)
+            print(f'[bench] all GEMMs: {tot_ms / args.steps:.2f} ms/step, roofline {tot_roof / args.steps:.2f} ms/step',
+                  file=sys.stderr)
         # dominant kernel = the instantiation with the largest share of the timed region
         dom = max(summ, key=lambda k: summ[k]['ms']) if summ else 'none'
         d = summ.get(dom, {'launches': 0, 'ms': 0.0, 'flops': 0.0})

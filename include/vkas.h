@@ -153,11 +153,11 @@ size_t vkas_layernorm_bwd_ws_bytes(long M, int Cp);
 /* gamma/beta (C), wproj (oc, C), bproj (oc) fp32 -> out[6*pw + 8] as laid out in vkas_head_desc */
 int vkas_pack_head_params(const float* gamma, const float* beta, const float* wproj, const float* bproj, int C, int oc,
                           int pw, float* out, void* stream);
-/* backward of the fused tail for one head: z (M, np) slice with stride ldz, its stats (M, 2), dproj (M, 8) fp32 = gradient
- * of the projection outputs -> dz (slice, stride lddz) and dparams[6*pw + 8] (same layout as the packed parameters). */
-int vkas_head_tail_bwd(const void* z, long ldz, const float* params, const float* stats, const float* dproj, void* dz,
-                       long lddz, float* dparams, float* ws, size_t ws_bytes, long M, int C, int np, int pw, int dtype,
-                       void* stream);
+/* backward of the fused tail for all heads of the launch at once: z / dz are the shared (M, sum np) buffers (strides ldz,
+ * lddz), hd the descriptor used in the forward (params, stats; proj unused), dproj[h] the (M, 8) fp32 gradients of head
+ * h's projection outputs -> dz and dparams[n_heads][6*pw + 8] (same layout as the packed parameters). */
+int vkas_head_tail_bwd(const void* z, long ldz, const vkas_head_desc* hd, const float* const* dproj, void* dz, long lddz,
+                       float* dparams, float* ws, size_t ws_bytes, long M, int dtype, void* stream);
 size_t vkas_head_tail_bwd_ws_bytes(long M, int pw);
 
 /* ---- block_scale / stochastic depth backward: convnext.py:56-58 ----------------------------------- */

@@ -17,6 +17,13 @@ namespace {
 
 constexpr int BK = 64;
 
+// Timing-only ablation switches for profiles/ablate_nt.py (never defined in the shipped build; results are wrong when
+// set): 1 no global loads in the K loop, 2 no LDS staging writes, 4 no barrier, 8 fragments read once, 16 no MFMA.
+#ifndef VKAS_ABL
+#define VKAS_ABL 0
+#endif
+constexpr int ABL = VKAS_ABL;
+
 __device__ __forceinline__ int swz_off(int row, int chunk) {  // element offset inside a [rows][64] bf16 tile
   return row * BK + ((chunk ^ (row & 7)) << 3);
 }
@@ -263,6 +270,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
   // Per K tile: first MFMA half | registers (tile kt+1, loaded one and a half iterations ago) -> LDS, reissue the
   // global loads for tile kt+2 | second MFMA half | barrier.  The LDS write latency and the global-load latency
   // both sit behind MFMA work instead of in front of the barrier.
+  bf16x8 fa_once[2][TM], fb_once[2][TN];
+  if constexpr ((ABL & 8) != 0) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa_once[s][i] = *reinterpret_cast<const bf16x8*>(lds + swz_off(wm * TM * 16 + i * 16 + frow, s * 4 + fchunk));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb_once[s][j] = *reinterpret_cast<const bf16x8*>(lds + BM * BK + swz_off(wn * TN * 16 + j * 16 + frow, s * 4 + fchunk));
+    }
+  }
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     const bf16_t* As = lds + buf * (BM + BN) * BK;
@@ -270,25 +289,47 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 fa[TM], fb[TN];
+      if constexpr ((ABL & 8) != 0) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        fa[i] = *reinterpret_cast<const bf16x8*>(As + swz_off(wm * TM * 16 + i * 16 + frow, s * 4 + fchunk));
+        for (int i = 0; i < TM; ++i) fa[i] = fa_once[s][i];
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        fb[j] = *reinterpret_cast<const bf16x8*>(Bs + swz_off(wn * TN * 16 + j * 16 + frow, s * 4 + fchunk));
-      __builtin_amdgcn_s_setprio(1);
+        for (int j = 0; j < TN; ++j) fb[j] = fb_once[s][j];
+      } else {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
+          fa[i] = *reinterpret_cast<const bf16x8*>(As + swz_off(wm * TM * 16 + i * 16 + frow, s * 4 + fchunk));
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+          fb[j] = *reinterpret_cast<const bf16x8*>(Bs + swz_off(wn * TN * 16 + j * 16 + frow, s * 4 + fchunk));
+      }
+      if constexpr ((ABL & 16) != 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[j]));
+      } else {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
       if (s == 0 && kt + 1 < nk) {
-        store_tile(buf ^ 1);
-        if (kt + 2 < nk) load_tile();
+        if constexpr ((ABL & 2) == 0) store_tile(buf ^ 1);
+        else {
+#pragma unroll
+          for (int i = 0; i < ACH; ++i) asm volatile("" ::"v"(ra[i]));
+#pragma unroll
+          for (int i = 0; i < BCH; ++i) asm volatile("" ::"v"(rb[i]));
+        }
+        if constexpr ((ABL & 1) == 0) {
+          if (kt + 2 < nk) load_tile();
+        }
       }
     }
-    __syncthreads();
+    if constexpr ((ABL & 4) == 0) __syncthreads();
   }
 
   // epilogue: the accumulators (lane = 4 consecutive channels of one pixel) go through LDS one wave-row at a time

@@ -10,7 +10,7 @@ int vkas_colreduce_finalize(const float* partial, long P, int n, int ldp, float*
 namespace {
 
 constexpr int G = 32;   // lanes per pixel row (C <= 224 -> at most 28 8-channel vectors)
-constexpr int R = 1;    // rows in flight per lane group (register budget: 64 accumulators for dgamma..dWproj)
+constexpr int R = 2;    // rows in flight per lane group
 
 __global__ void pack_head_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                         const float* __restrict__ wproj, const float* __restrict__ bproj, int C, int oc,
@@ -30,52 +30,83 @@ __global__ void pack_head_params_kernel(const float* __restrict__ gamma, const f
   out[i] = v;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 3) void head_tail_bwd_kernel(const T* __restrict__ z, long ldz,
+// One launch handles ALL heads of a pass: lane group g (32 lanes) of a workgroup works on head g % NH of row g / NH, so a
+// workgroup reads and writes whole rows of the shared (M, sum np) buffers (the per-head column slices are not
+// 128-byte aligned; per-head launches left every row with partially written cache lines).
+struct HeadBwdArgs {
+  int n_heads, pw;
+  int n0[4], np[4], c[4];
+  const float* dproj[4];  // (M, 8) fp32 each
+};
+
+template <typename T, int NH>
+__global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict__ z, long ldz,
                                                             const float* __restrict__ params,
-                                                            const float* __restrict__ stats,
-                                                            const float* __restrict__ dproj, T* __restrict__ dz, long lddz,
-                                                            float* __restrict__ partial, long M, int C, int np, int pw,
-                                                            long rows_per_block) {
-  const int nvec = np >> 3;
+                                                            const float* __restrict__ stats, HeadBwdArgs a,
+                                                            T* __restrict__ dz, long lddz, float* __restrict__ partial,
+                                                            long M, long rows_per_block) {
+  static_assert(NH == 1 || NH == 2 || NH == 4, "lane groups per row");
+  constexpr int rpi = 256 / G / NH;  // rows per sub-iteration
   const int gl = threadIdx.x & (G - 1);
-  const int rl = threadIdx.x / G;
-  constexpr int rpi = 256 / G;
+  const int grp = threadIdx.x / G;
+  const int head = grp % NH, rl = grp / NH;
+  const bool hok = head < a.n_heads;
+  const int pw = a.pw, PS = 6 * pw + 8;
+  const int C = hok ? a.c[head] : 1, np = hok ? a.np[head] : 0, n0 = hok ? a.n0[head] : 0;
+  const float* hstats = stats + (long)head * M * 2;
+  const float* hdproj = hok ? a.dproj[head] : nullptr;
+  const int nvec = np >> 3;
   const long mbeg = (long)blockIdx.x * rows_per_block;
   const long mend = mbeg + rows_per_block < M ? mbeg + rows_per_block : M;
-  const bool vok = gl < nvec;
-  float gm[8], bt[8], wp[4][8];
+  const bool vok = hok && gl < nvec;
+  // gamma | beta | Wproj[4] of every head live in LDS (each lane re-reads its 8-channel slice per row)
+  __shared__ __attribute__((aligned(16))) float sp[NH * 6 * 224];
+  for (int i = threadIdx.x; i < NH * 6 * pw; i += 256) {
+    const int h = i / (6 * pw), r = i - h * 6 * pw;
+    sp[i] = h < a.n_heads ? params[(long)h * PS + r] : 0.f;
+  }
+  __syncthreads();
+  const float* hp = sp + head * 6 * pw;
   float dg[8], db[8], dwp[4][8], dbp[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int c = 0; c < 8; ++c) { gm[c] = 0.f; bt[c] = 0.f; dg[c] = 0.f; db[c] = 0.f; }
+  for (int c = 0; c < 8; ++c) { dg[c] = 0.f; db[c] = 0.f; }
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { wp[q][c] = 0.f; dwp[q][c] = 0.f; }
-  if (vok) {
-    load8(params + gl * 8, gm);
-    load8(params + pw + gl * 8, bt);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) load8(params + (2 + q) * pw + gl * 8, wp[q]);
-  }
+    for (int c = 0; c < 8; ++c) dwp[q][c] = 0.f;
   for (long m0 = mbeg; m0 < mend; m0 += (long)R * rpi) {
     float xh[R][8], g[R][8], mean[R], rstd[R];
     float4 dp[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const long m = m0 + (long)r * rpi + rl;
-      const bool ok = m < mend;
-      mean[r] = ok ? stats[2 * m] : 0.f;
-      rstd[r] = ok ? stats[2 * m + 1] : 0.f;
-      dp[r] = ok ? *reinterpret_cast<const float4*>(dproj + m * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = hok && m < mend;
+      mean[r] = ok ? hstats[2 * m] : 0.f;
+      rstd[r] = ok ? hstats[2 * m + 1] : 0.f;
+      dp[r] = ok ? *reinterpret_cast<const float4*>(hdproj + m * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int c = 0; c < 8; ++c) xh[r][c] = 0.f;
-      if (ok && vok) load8(z + m * ldz + gl * 8, xh[r]);
+      if (ok && vok) load8(z + m * ldz + n0 + gl * 8, xh[r]);
+    }
+    float gm[8], bt[8], wp[4][8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { gm[c] = 0.f; bt[c] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) wp[q][c] = 0.f;
+    if (vok) {
+      int lo = gl * 8;
+      asm volatile("" : "+v"(lo));  // opaque per iteration: keeps these loads in the loop (LICM would pin 48 VGPRs)
+      load8(hp + lo, gm);
+      load8(hp + pw + lo, bt);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) load8(hp + (2 + q) * pw + lo, wp[q]);
     }
     float s1[R], s2[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const bool ok = m0 + (long)r * rpi + rl < mend;
+      const bool ok = hok && m0 + (long)r * rpi + rl < mend;
       const float d4[4] = {dp[r].x, dp[r].y, dp[r].z, dp[r].w};
       s1[r] = 0.f;
       s2[r] = 0.f;
@@ -95,12 +126,12 @@ __global__ __launch_bounds__(256, 3) void head_tail_bwd_kernel(const T* __restri
           cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
           pdf = 0.39894228040143268f * __expf(-0.5f * u * u);
         }
-        const float a = cok ? u * cdf : 0.f;
+        const float act = cok ? u * cdf : 0.f;
         float da = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           da = fmaf(d4[q], wp[q][c], da);
-          dwp[q][c] = fmaf(d4[q], a, dwp[q][c]);
+          dwp[q][c] = fmaf(d4[q], act, dwp[q][c]);
         }
         const float gg = cok ? da * fmaf(u, pdf, cdf) : 0.f;
         xh[r][c] = h;
@@ -129,12 +160,12 @@ __global__ __launch_bounds__(256, 3) void head_tail_bwd_kernel(const T* __restri
       float o[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) o[c] = (gl * 8 + c < C) ? rstd[r] * (g[r][c] * gm[c] - s1[r] - xh[r][c] * s2[r]) : 0.f;
-      store8(dz + m * lddz + gl * 8, o);
+      store8(dz + m * lddz + n0 + gl * 8, o);
     }
   }
-  // reduce the per-thread column sums over the 8 row lanes; partial row = dgamma | dbeta | dWp[4] | dbp[8]
+  // reduce the per-thread column sums over the row lanes; partial row per head = dgamma | dbeta | dWp[4] | dbp[8]
   __shared__ float red[256 * 8];
-  float* prow = partial + (long)blockIdx.x * (6 * pw + 8);
+  float* prow = partial + ((long)blockIdx.x * NH + head) * PS;
   auto reduce_store = [&](const float* vals, int dst_off) {
     __syncthreads();
 #pragma unroll
@@ -145,7 +176,7 @@ __global__ __launch_bounds__(256, 3) void head_tail_bwd_kernel(const T* __restri
       for (int c = 0; c < 8; ++c) {
         float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < rpi; ++r) s += red[(r * G + gl) * 8 + c];
+        for (int r = 0; r < rpi; ++r) s += red[(((r * NH + head) * G) + gl) * 8 + c];
         prow[dst_off + gl * 8 + c] = vok ? s : 0.f;
       }
     }
@@ -159,17 +190,17 @@ __global__ __launch_bounds__(256, 3) void head_tail_bwd_kernel(const T* __restri
 #pragma unroll
   for (int c = 0; c < 8; ++c) red[threadIdx.x * 8 + c] = b8[c];
   __syncthreads();
-  if (threadIdx.x < 8) {
+  if (rl == 0 && gl < 8) {
     float s = 0.f;
-    for (int r = 0; r < rpi; ++r) s += red[(r * G) * 8 + threadIdx.x];  // gl == 0 lanes hold the row sums of d(proj)
-    prow[6 * pw + threadIdx.x] = s;
+    for (int r = 0; r < rpi; ++r) s += red[((r * NH + head) * G) * 8 + gl];  // gl == 0 lanes hold the row sums of d(proj)
+    prow[6 * pw + gl] = s;
   }
 }
 
 static inline long ht_rows_per_block(long M) {
   long r = vkas_cdiv(M > 0 ? M : 1, 1024);
   if (r < 32) r = 32;
-  const long q = (long)R * (256 / G);
+  const long q = (long)R * (256 / G);  // multiple of R * rpi for every NH
   return vkas_cdiv(r, q) * q;
 }
 
@@ -187,31 +218,49 @@ extern "C" int vkas_pack_head_params(const float* gamma, const float* beta, cons
 }
 
 extern "C" size_t vkas_head_tail_bwd_ws_bytes(long M, int pw) {
-  return (size_t)vkas_cdiv(M > 0 ? M : 1, ht_rows_per_block(M)) * (size_t)(6 * pw + 8) * sizeof(float);
+  return (size_t)vkas_cdiv(M > 0 ? M : 1, ht_rows_per_block(M)) * 4 * (size_t)(6 * pw + 8) * sizeof(float);
 }
 
-extern "C" int vkas_head_tail_bwd(const void* z, long ldz, const float* params, const float* stats, const float* dproj,
-                                  void* dz, long lddz, float* dparams, float* ws, size_t ws_bytes, long M, int C, int np,
-                                  int pw, int dtype, void* stream) {
-  VKAS_CHECK(z && params && stats && dproj && dz && dparams && ws, "vkas_head_tail_bwd: null pointer");
-  VKAS_CHECK(C > 0 && np % 8 == 0 && C <= np && np <= pw && pw % 8 == 0 && pw <= 224, "vkas_head_tail_bwd: bad C=%d np=%d pw=%d",
-             C, np, pw);
-  VKAS_CHECK(ldz >= np && lddz >= np && ldz % 8 == 0 && lddz % 8 == 0 && vkas_aligned16(z) && vkas_aligned16(dz) &&
-                 vkas_aligned16(dproj) && vkas_aligned16(params),
+extern "C" int vkas_head_tail_bwd(const void* z, long ldz, const vkas_head_desc* hd, const float* const* dproj, void* dz,
+                                  long lddz, float* dparams, float* ws, size_t ws_bytes, long M, int dtype, void* stream) {
+  VKAS_CHECK(z && hd && dproj && dz && dparams && ws && hd->params && hd->stats, "vkas_head_tail_bwd: null pointer");
+  const int pw = hd->pw, nh = hd->n_heads;
+  VKAS_CHECK(nh >= 1 && nh <= 4 && pw % 8 == 0 && pw >= 8 && pw <= 224, "vkas_head_tail_bwd: bad descriptor");
+  HeadBwdArgs a;
+  a.n_heads = nh;
+  a.pw = pw;
+  for (int h = 0; h < 4; ++h) {
+    a.n0[h] = h < nh ? hd->n0[h] : 0;
+    a.np[h] = h < nh ? hd->np[h] : 0;
+    a.c[h] = h < nh ? hd->c[h] : 1;
+    a.dproj[h] = h < nh ? dproj[h] : nullptr;
+    if (h < nh) {
+      VKAS_CHECK(a.np[h] % 8 == 0 && a.np[h] > 0 && a.np[h] <= pw && a.c[h] > 0 && a.c[h] <= a.np[h] && a.n0[h] % 8 == 0 &&
+                     a.n0[h] + a.np[h] <= ldz && a.n0[h] + a.np[h] <= lddz && a.dproj[h] && vkas_aligned16(a.dproj[h]),
+                 "vkas_head_tail_bwd: bad head %d", h);
+    }
+  }
+  VKAS_CHECK(ldz % 8 == 0 && lddz % 8 == 0 && vkas_aligned16(z) && vkas_aligned16(dz) && vkas_aligned16(hd->params),
              "vkas_head_tail_bwd: bad strides/alignment");
   VKAS_CHECK(ws_bytes >= vkas_head_tail_bwd_ws_bytes(M, pw), "vkas_head_tail_bwd: workspace too small");
   hipStream_t st = vkas_stream(stream);
-  const int n = 6 * pw + 8;
+  const int PS = 6 * pw + 8;
   if (M <= 0) {
-    (void)hipMemsetAsync(dparams, 0, n * sizeof(float), st);
+    (void)hipMemsetAsync(dparams, 0, (size_t)nh * PS * sizeof(float), st);
     return VKAS_OK;
   }
   const long rpb = ht_rows_per_block(M);
   const long P = vkas_cdiv(M, rpb);
+  const int NH = nh == 1 ? 1 : (nh == 2 ? 2 : 4);
   VKAS_DISPATCH_DTYPE(dtype, "vkas_head_tail_bwd", {
-    head_tail_bwd_kernel<T><<<(unsigned)P, 256, 0, st>>>((const T*)z, ldz, params, stats, dproj, (T*)dz, lddz, ws, M, C, np, pw,
-                                                         rpb);
+    if (NH == 1)
+      head_tail_bwd_kernel<T, 1><<<(unsigned)P, 256, 0, st>>>((const T*)z, ldz, hd->params, hd->stats, a, (T*)dz, lddz, ws, M, rpb);
+    else if (NH == 2)
+      head_tail_bwd_kernel<T, 2><<<(unsigned)P, 256, 0, st>>>((const T*)z, ldz, hd->params, hd->stats, a, (T*)dz, lddz, ws, M, rpb);
+    else
+      head_tail_bwd_kernel<T, 4><<<(unsigned)P, 256, 0, st>>>((const T*)z, ldz, hd->params, hd->stats, a, (T*)dz, lddz, ws, M, rpb);
   })
   VKAS_LAUNCH_CHECK("head_tail_bwd");
-  return vkas_colreduce_finalize(ws, P, n, n, dparams, 0, st);
+  // partial rows are (block, lane-group head) pairs: NH * PS floats per block; heads beyond n_heads are zero
+  return vkas_colreduce_finalize(ws, P, nh * PS, NH * PS, dparams, 0, st);
 }

@@ -117,11 +117,11 @@ class LaunchTimer:
     recorded on torch's current stream, which is the stream the kernels are launched on."""
 
     def __init__(self):
-        self.records = []  # (kind, start_event, end_event, flops, M, N, K)
+        self.records = []  # (kind, start_event, end_event, flops, M, N, K, algorithmic bytes)
 
     def summary(self):
         out = {}
-        for kind, s, e, flops, M, N, K in self.records:
+        for kind, s, e, flops, M, N, K, _ in self.records:
             d = out.setdefault(kind, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
             d['launches'] += 1
             d['ms'] += s.elapsed_time(e)
@@ -132,14 +132,14 @@ class LaunchTimer:
 TIMER: Optional[LaunchTimer] = None
 
 
-def _timed(kind, x, flops, M, N, K, fn):
+def _timed(kind, x, flops, M, N, K, fn, nbytes=0.0):
     if TIMER is None:
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     r = fn()
     e.record()
-    TIMER.records.append((kind, s, e, flops, M, N, K))
+    TIMER.records.append((kind, s, e, flops, M, N, K, nbytes))
     return r
 
 
@@ -160,9 +160,11 @@ def conv_gemm(x: torch.Tensor, geom: ConvGeom, Bw: torch.Tensor, Np: int, out: t
             kind = 'gemm_nt_mfma<%s>' % ('128x128' if t == 1 else '256x%d' % t)
         else:
             kind = 'gemm_nt_simple'
+        es = x.element_size()
+        nbytes = (geom.B * geom.Hin * geom.Win * geom.Cp + M * Np * (1 + (out2 is not None) + (aux is not None))) * es
         return _timed(kind, x, 2.0 * M * N * K, M, N, K,
                       lambda: _conv_gemm(x, geom, Bw, Np, out, mode, bias, out2, aux, colscale, rowscale, rows_per_image,
-                                         patch, patch_hw, patch_Cp, head))
+                                         patch, patch_hw, patch_Cp, head), nbytes)
     return _conv_gemm(x, geom, Bw, Np, out, mode, bias, out2, aux, colscale, rowscale, rows_per_image, patch, patch_hw,
                       patch_Cp, head)
 
@@ -201,7 +203,8 @@ def conv_wgrad(x: torch.Tensor, geom: ConvGeom, dy: torch.Tensor, Np: int, nk=No
     else:
         kind = 'gemm_tn_simple'
     N, Kl = nk if nk is not None else (Np, K)
-    return _timed(kind, x, 2.0 * M * N * Kl, M, N, Kl, run)
+    nbytes = (geom.B * geom.Hin * geom.Win * geom.Cp + M * Np) * x.element_size() + 4.0 * Np * K
+    return _timed(kind, x, 2.0 * M * N * Kl, M, N, Kl, run, nbytes)
 
 
 def unpack_wgrad(gw: torch.Tensor, shape4, Np: int, Cp: int) -> torch.Tensor:
@@ -506,15 +509,22 @@ class HeadsFused(Function):
         dz = new_act(B, H, W, Nt, x)
         dparams = torch.empty((n_heads, 6 * pw + 8), dtype=_FLOAT, device=dev)
         nbytes = lib.vkas_head_tail_bwd_ws_bytes(M, pw)
+        ws = _ws(nbytes, dev)
+        head = _lib.HeadDesc()
+        head.n_heads, head.pw = n_heads, pw
         off = 0
+        dps = []
+        ptrs = (ctypes.c_void_p * 4)()
         for h in range(n_heads):
+            head.n0[h], head.np[h], head.c[h], head.oc[h] = off, nps[h], cs[h], ocs[h]
+            off += nps[h]
             dp = dprojs[h]
             dp = torch.zeros((B, H, W, 8), dtype=_FLOAT, device=dev) if dp is None else dp.contiguous().float()
-            zs, dzs = z[..., off:off + nps[h]], dz[..., off:off + nps[h]]
-            ws = _ws(nbytes, dev)
-            check(lib.vkas_head_tail_bwd(_p(zs), Nt, _p(hp[h]), _p(stats[h]), _p(dp), _p(dzs), Nt, _p(dparams[h]), _p(ws),
-                                         nbytes, M, cs[h], nps[h], pw, _dt(x), _stream()), 'head_tail_bwd')
-            off += nps[h]
+            dps.append(dp)
+            ptrs[h] = dp.data_ptr()
+        head.params, head.stats, head.proj = hp.data_ptr(), stats.data_ptr(), None
+        check(lib.vkas_head_tail_bwd(_p(z), Nt, ctypes.byref(head), ptrs, _p(dz), Nt, _p(dparams), _p(ws), nbytes, M,
+                                     _dt(x), _stream()), 'head_tail_bwd')
         geom = _geom(B, H, W, H, W, Cp, act_ld(x), 3, 3, 1, 1)
         gwp, gbp = conv_wgrad(x, geom, dz, Nt, nk=(sum(cs), C * 9), with_bias=True)
         gw = unpack_wgrad(gwp, (N, C, 3, 3), Nt, Cp)
