@@ -77,6 +77,9 @@ CONV_CASES = [
     (1, 3, 32, 64, 16, 2, 2, 0),
     (3, 200, 17, 9, 136, 1, 1, 0),
     (1, 64, 6, 5, 3072, 1, 1, 0),  # > 2048 output channels (stage-3 MLP width): bias-grad column sums in two passes
+    # rows of whole 256-pixel tiles, M >= 16384: the 3x3 row-slab kernel (fwd and dgrad), channel-block tails, both halos
+    (2, 72, 33, 256, 200, 3, 1, 1),
+    (1, 64, 34, 512, 384, 3, 1, 1),
 ]
 
 
@@ -386,13 +389,15 @@ def test_clip_adamw_matches_torch():
 
 
 # ------------------------------------------------------------------------------------------ fused head tail
+@pytest.mark.parametrize('hw', [(128, 136), (66, 256)], ids=['generic', 'rowslab'])
 @pytest.mark.parametrize('chans', [((40, 33), (1, 4)), ((192, 193, 194, 194), (1, 2, 4, 4)), ((96,), (3,))])
-def test_heads_fused_matches_unfused_and_fp64(chans):
+def test_heads_fused_matches_unfused_and_fp64(chans, hw):
     """Conv3x3 + per-head LayerNorm + GELU + Linear(C -> oc) fused into the GEMM epilogue (bf16) vs the same math in fp64
     on the host, forward and every gradient (input, conv weight / bias, gamma, beta, projection weight / bias)."""
     ops = ops_mod()
     cs, ocs = chans
-    B, H, W, Cin = 1, 128, 136, 64
+    B, Cin = 1, 64
+    H, W = hw
     dtype = torch.bfloat16
     x = q(rnd((B, Cin, H, W), 50), dtype)
     convs = [(q(rnd((c, Cin, 3, 3), 51 + i, 1.0 / math.sqrt(Cin * 9)), dtype), rnd((c,), 61 + i, 0.1)) for i, c in enumerate(cs)]

@@ -11,6 +11,8 @@
 //    transposing LDS read (ds_read_b64_tr_b16).  Split over M, fp32 atomics into the (small) gw.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gemm_parts.h"
 
 namespace {
@@ -110,6 +112,51 @@ __device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head,
     float* st = e.head.stats + ((long)head * M + m) * 2;
     st[0] = mean;
     st[1] = rstd;
+  }
+}
+
+// Epilogue shared by the NT kernels: the accumulators (lane = 4 consecutive channels of one pixel) go through LDS one
+// wave-row at a time so that every global access of the fused epilogue is a coalesced 16-byte piece of an output row.
+// `stage` is the kernel's (idle) tile storage; the caller guarantees that every wave has finished reading it.
+template <int WM, int WN, int TM, int TN, bool HEAD>
+__device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[TM][TN], float* stage, const vkas_epilogue& e, int tile_n,
+                                            long m0, long M, int n0, int n_end, int tid) {
+  constexpr int NTHR = WM * WN * 64;
+  constexpr int BN = WN * TN * 16;
+  constexpr int EP = BN + 4;            // fp32 row pitch: pitch % 32 == 4 keeps the 16-byte writes conflict free
+  constexpr int ER = TM * 16;           // rows per pass
+  constexpr int VPR = BN / 8;           // 8-channel vectors per row
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+#pragma unroll 1
+  for (int pass = 0; pass < WM; ++pass) {
+    if (wm == pass) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          *reinterpret_cast<f32x4*>(stage + (i * 16 + (lane & 15)) * EP + wn * TN * 16 + j * 16 + (lane >> 4) * 4) =
+              acc[i][j];
+    }
+    __syncthreads();
+    if constexpr (HEAD) {
+      head_tail_rows<NTHR, ER, EP, VPR>(e, tile_n, stage, m0 + (long)pass * ER, M, n0, n_end - n0, tid);
+    } else {
+      for (int t = tid; t < ER * VPR; t += NTHR) {
+        const int row = t / VPR, c8 = t - row * VPR;
+        const long m = m0 + pass * ER + row;
+        const int n = n0 + c8 * 8;
+        if (m < M && n < n_end) {
+          float v[8];
+          const float4 lo = *reinterpret_cast<const float4*>(stage + row * EP + c8 * 8);
+          const float4 hi = *reinterpret_cast<const float4*>(stage + row * EP + c8 * 8 + 4);
+          v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+          epi_store8<bf16_t>(e, m, n, v);
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -332,42 +379,198 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
     if constexpr ((ABL & 4) == 0) __syncthreads();
   }
 
-  // epilogue: the accumulators (lane = 4 consecutive channels of one pixel) go through LDS one wave-row at a time
-  // so that every global access of the fused epilogue is a coalesced 16-byte piece of an output row.
-  constexpr int EP = BN + 4;            // fp32 row pitch: pitch % 32 == 4 keeps the 16-byte writes conflict free
-  constexpr int ER = TM * 16;           // rows per pass
-  constexpr int VPR = BN / 8;           // 8-channel vectors per row
-  static_assert(ER * EP * 4 <= 2 * (BM + BN) * BK * 2, "epilogue staging must fit the tile buffers");
-  float* stage = reinterpret_cast<float*>(lds);
-#pragma unroll 1
-  for (int pass = 0; pass < WM; ++pass) {
-    if (wm == pass) {
+  static_assert(TM * 16 * (BN + 4) * 4 <= 2 * (BM + BN) * BK * 2, "epilogue staging must fit the tile buffers");
+  nt_epilogue<WM, WN, TM, TN, HEAD>(acc, reinterpret_cast<float*>(lds), e, tile_n, m0, M, n0, n_end, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Row-slab kernel for 3x3 / stride 1 / pad 1 convolutions whose rows are a multiple of 256 pixels wide (the head convs
+// and their input gradients at 8x512x512: ~45% of the step).  The generic kernel above is bound by L2 -> CU operand
+// traffic there (a 256x192 tile moves 57 KB per 64-deep K step, ~17 TB/s chip-wide, the measured L2 gather rate), so
+// this kernel cuts the bytes instead of chasing issue slots:
+//  * an M tile is 256 consecutive pixels of ONE image row.  For input row ky and a 64-channel block, the 258-pixel
+//    slab (tile + one halo pixel each side) is staged once and serves the three kx taps as row-shifted fragment
+//    reads: A traffic / 3.  K is walked as (ky, channel block, kx); the weights keep their [n][ky][kx][c] layout.
+//  * operands go global -> LDS directly (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass.  The
+//    LDS image of one wave instruction is 8 rows x 128 B, lane-linear; the XOR swizzle the fragment reads expect is
+//    applied to the per-lane SOURCE chunk.  Out-of-range lanes (zero padding, channel / N tails) use an offset
+//    beyond the descriptor: the hardware writes zeros for them.
+//  * 2 slab buffers + a ring of 3 weight tiles; every sub-step issues the weight tile two sub-steps ahead and a
+//    share of the next slab, then waits with a counted vmcnt (only this sub-step's own issues stay in flight) in
+//    front of a raw s_barrier.  A staged buffer is read only after the barrier that follows the wait retiring it,
+//    and re-filled only after the barrier that ends its last reading sub-step.
+template <int TN, bool HEAD>
+__global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
+                                                                const bf16_t* __restrict__ Bw, int Np, long M, int K,
+                                                                vkas_epilogue e, unsigned a_bytes, unsigned b_bytes) {
+  constexpr int WM = 4, WN = 2, TM = 4;
+  constexpr int BM = 256, BN = WN * TN * 16;
+  constexpr int SLAB = 264 * BK;             // rows 0..255 tile pixels, 256 / 257 left / right halo, 258..263 unused
+  constexpr int BT = BN * BK;
+  constexpr int NWI = BN / 8;                // wave instructions (8 rows each) per weight tile
+  constexpr int NBQ = (NWI + 7) / 8;         // ... per wave (waves >= RAG issue one less when NWI % 8 != 0)
+  constexpr int RAG = NWI % 8;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  __shared__ __attribute__((aligned(1024))) bf16_t lds[2 * SLAB + 3 * BT];
+  static_assert(TM * 16 * (BN + 4) * 4 <= (2 * SLAB + 3 * BT) * 2, "epilogue staging must fit");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  // tile order: as in gemm_nt_mfma_kernel (contiguous runs per XCD, N tiles fastest)
+  const unsigned ntile_n = HEAD ? (unsigned)e.head.n_heads : (unsigned)((Np + BN - 1) / BN);
+  const unsigned total = gridDim.x;
+  const unsigned xcd = blockIdx.x & 7u, slot8 = blockIdx.x >> 3;
+  const unsigned q8 = total >> 3, r8 = total & 7u;
+  const unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
+  const long m0 = (long)(tile / ntile_n) * BM;
+  const int tile_n = (int)(tile % ntile_n);
+  const int n0 = HEAD ? e.head.n0[tile_n] : tile_n * BN;
+  const int n_end = HEAD ? n0 + e.head.np[tile_n] : Np;
+  const int H = g.Hin, W = g.Win, Cp = g.Cp;
+  const int hw = H * W;
+  const int bimg = (int)(m0 / hw);
+  const int rem = (int)(m0 - (long)bimg * hw);
+  const int oy = rem / W, ox0 = rem - oy * W;  // the tile is pixels ox0 .. ox0+255 of image row (bimg, oy)
+
+  // per-lane staging constants: a wave instruction fills 8 rows x 8 chunk positions; the lane at (row lr, position
+  // cpos) fetches logical chunk cpos ^ lr (all row bases are multiples of 8)
+  const int lr = lane >> 3;
+  const int cl = (lane & 7) ^ lr;
+  const unsigned row_pitch = (unsigned)W * (unsigned)g.ldx * 2u;  // bytes between image rows
+  unsigned a_off[4];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+  for (int q = 0; q < 4; ++q)
+    a_off[q] = ((unsigned)((bimg * H + oy - 1) * W + ox0 + (q * 8 + wave) * 8 + lr) * (unsigned)g.ldx + (unsigned)(cl * 8)) * 2u;
+  // halo: lanes 0, 1 of wave w carry chunks 2w, 2w+1 of the 16 halo chunks (row 256: pixel ox0-1, row 257: ox0+256)
+  const int hc = wave * 2 + (lane & 1);
+  const int hrow = hc >> 3;
+  const int hcl = (hc & 7) ^ hrow;
+  const int hpix = hrow == 0 ? ox0 - 1 : ox0 + BM;
+  const bool h_ok = (unsigned)hpix < (unsigned)W;
+  const unsigned h_off = ((unsigned)((bimg * H + oy - 1) * W + hpix) * (unsigned)g.ldx + (unsigned)(hcl * 8)) * 2u;
+  unsigned b_off[NBQ];
+  bool b_ok[NBQ];
+#pragma unroll
+  for (int q = 0; q < NBQ; ++q) {
+    const int r = (q * 8 + wave) * 8 + lr;
+    b_ok[q] = r < BN && n0 + r < n_end;
+    b_off[q] = ((unsigned)(n0 + r) * (unsigned)K + (unsigned)(cl * 8)) * 2u;
+  }
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)x, (short)0, (int)a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)Bw, (short)0, (int)b_bytes, 0x00020000);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  // slab part `part` (0, 1: wave instructions {0,1} / {2,3} of the tile rows; 2: halo) of step (ky, cb) -> slab sb
+  auto issue_a = [&](int part, int ky, int cb, int sb) {
+    const bool row_ok = (unsigned)(oy - 1 + ky) < (unsigned)H;
+    const unsigned step_off = (unsigned)ky * row_pitch + (unsigned)cb * 128u;
+    bf16_t* dst = lds + sb * SLAB;
+    if (part < 2) {
+      const bool ok = row_ok && cb * 64 + cl * 8 < Cp;
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const int q = part * 2 + qq;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr)(dst + (q * 8 + wave) * 512), 16,
+                                                 ok ? a_off[q] + step_off : OOB, 0, 0, 0);
+      }
+    } else {
+      const bool ok = row_ok && h_ok && cb * 64 + hcl * 8 < Cp;
+      if (lane < 2)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr)(dst + 256 * BK + wave * 16), 16,
+                                                 ok ? h_off + step_off : OOB, 0, 0, 0);
+    }
+  };
+  // weight tile of (ky, kx, cb) -> ring slot
+  auto issue_b = [&](int ky, int kx, int cb, int slot) {
+    const unsigned step_off = ((unsigned)((ky * 3 + kx) * Cp) + (unsigned)cb * 64u) * 2u;
+    const bool c_ok = cb * 64 + cl * 8 < Cp;
+    bf16_t* dst = lds + 2 * SLAB + slot * BT;
+#pragma unroll
+    for (int q = 0; q < NBQ; ++q) {
+      if (RAG != 0 && q == NBQ - 1 && wave >= RAG) break;  // wave-uniform
+      const unsigned voff = (c_ok && b_ok[q]) ? b_off[q] + step_off : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr)(dst + (q * 8 + wave) * 512), 16, voff, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int NCB = (Cp + 63) >> 6;
+  const int NS = 3 * NCB;  // steps (ky, cb); three kx sub-steps each
+  issue_a(0, 0, 0, 0);
+  issue_a(1, 0, 0, 0);
+  issue_a(2, 0, 0, 0);
+  issue_b(0, 0, 0, 0);
+  issue_b(0, 1, 0, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  const int frow = lane & 15;
+  const int fchunk = lane >> 4;
+  int ky = 0, cb = 0;
+  for (int s = 0; s < NS; ++s) {
+    const int sb = s & 1;
+    const bool more = s + 1 < NS;
+    int ky1 = ky, cb1 = cb + 1;
+    if (cb1 == NCB) { cb1 = 0; ky1 = ky + 1; }
+    const bf16_t* As = lds + sb * SLAB;
+    auto sub = [&](auto kxc) {
+      constexpr int kx = decltype(kxc)::value;
+      // issue: share of the next slab, weight tile two sub-steps ahead
+      if (more) {
+        if constexpr (kx == 0) { issue_a(0, ky1, cb1, sb ^ 1); issue_a(2, ky1, cb1, sb ^ 1); }
+        if constexpr (kx == 1) issue_a(1, ky1, cb1, sb ^ 1);
+      }
+      if constexpr (kx == 0) issue_b(ky, 2, cb, 2);
+      else if (more) issue_b(ky1, kx - 1, cb1, kx - 1);
+      const bf16_t* Bs = lds + 2 * SLAB + kx * BT;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bf16x8 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int r = wm * 64 + i * 16 + frow;      // tile pixel
+          int sr = r + kx - 1;                         // slab row of the tap's pixel
+          if (kx == 0 && i == 0) sr = (sr < 0) ? 256 : sr;
+          if (kx == 2 && i == TM - 1) sr = (sr > 255) ? 257 : sr;
+          fa[i] = *reinterpret_cast<const bf16x8*>(As + swz_off(sr, h * 4 + fchunk));
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          *reinterpret_cast<f32x4*>(stage + (i * 16 + (lane & 15)) * EP + wn * TN * 16 + j * 16 + (lane >> 4) * 4) =
-              acc[i][j];
-    }
-    __syncthreads();
-    if constexpr (HEAD) {
-      head_tail_rows<NTHR, ER, EP, VPR>(e, tile_n, stage, m0 + (long)pass * ER, M, n0, n_end - n0, tid);
-    } else {
-      for (int t = tid; t < ER * VPR; t += NTHR) {
-        const int row = t / VPR, c8 = t - row * VPR;
-        const long m = m0 + pass * ER + row;
-        const int n = n0 + c8 * 8;
-        if (m < M && n < n_end) {
-          float v[8];
-          const float4 lo = *reinterpret_cast<const float4*>(stage + row * EP + c8 * 8);
-          const float4 hi = *reinterpret_cast<const float4*>(stage + row * EP + c8 * 8 + 4);
-          v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-          epi_store8<bf16_t>(e, m, n, v);
-        }
+          fb[j] = *reinterpret_cast<const bf16x8*>(Bs + swz_off(wn * TN * 16 + j * 16 + frow, h * 4 + fchunk));
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
       }
-    }
-    __syncthreads();
+      // everything issued before this sub-step has landed (own share); the barrier makes that true for every wave's
+      constexpr int NA = kx == 0 ? 3 : (kx == 1 ? 2 : 0);
+      if (more) {
+        if (RAG != 0 && wave >= RAG) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NBQ - (RAG != 0 ? 1 : 0)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NBQ) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+    sub(std::integral_constant<int, 0>{});
+    sub(std::integral_constant<int, 1>{});
+    sub(std::integral_constant<int, 2>{});
+    ky = ky1;
+    cb = cb1;
   }
+  nt_epilogue<WM, WN, TM, TN, HEAD>(acc, reinterpret_cast<float*>(lds), e, tile_n, m0, M, n0, n_end, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -660,6 +863,27 @@ int vkas_gemm_nt_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* B
   }
   const bool big = choice != 1;
   const int bn = big ? choice : 128;
+  // 3x3 / stride 1 / pad 1 with rows of whole 256-pixel tiles: the row-slab kernel
+  static const bool no_slab = getenv("VKAS_NT_NOSLAB") != nullptr;
+  const long a_bytes = (((long)g->B * g->Hin * g->Win - 1) * g->ldx + g->Cp) * 2;
+  const long b_bytes = (long)Np * K * 2;
+  if (big && !no_slab && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1 && g->Hout == g->Hin &&
+      g->Wout == g->Win && g->Win % 256 == 0 && a_bytes < 0xFFFFFFF0L && b_bytes < 0xFFFFFFF0L) {
+    const bool head = e->mode == VKAS_EPI_HEAD;
+    const long ntn = head ? e->head.n_heads : vkas_cdiv(Np, bn);
+    dim3 grid((unsigned)((M / 256) * ntn));
+    const bf16_t* xp = (const bf16_t*)x;
+    const bf16_t* bp = (const bf16_t*)Bw;
+#define VKAS_SLAB(TNV)                                                                                                  \
+  if (head) conv3x3_slab_mfma_kernel<TNV, true><<<grid, 512, 0, st>>>(xp, *g, bp, Np, M, K, *e, (unsigned)a_bytes, (unsigned)b_bytes); \
+  else conv3x3_slab_mfma_kernel<TNV, false><<<grid, 512, 0, st>>>(xp, *g, bp, Np, M, K, *e, (unsigned)a_bytes, (unsigned)b_bytes);
+    if (bn == 224) { VKAS_SLAB(7) }
+    else if (bn == 192) { VKAS_SLAB(6) }
+    else { VKAS_SLAB(4) }
+#undef VKAS_SLAB
+    VKAS_LAUNCH_CHECK("conv3x3_slab_mfma");
+    return VKAS_OK;
+  }
   if (!big) launch_nt<2, 2, 4, 4>(x, g, Bw, Np, M, K, e, st);
   else if (bn == 224) launch_nt<4, 2, 4, 7>(x, g, Bw, Np, M, K, e, st);
   else if (bn == 192) launch_nt<4, 2, 4, 6>(x, g, Bw, Np, M, K, e, st);
