@@ -438,10 +438,10 @@ __global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __
   const int lr = lane >> 3;
   const int cl = (lane & 7) ^ lr;
   const unsigned row_pitch = (unsigned)W * (unsigned)g.ldx * 2u;  // bytes between image rows
-  unsigned a_off[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    a_off[q] = ((unsigned)((bimg * H + oy - 1) * W + ox0 + (q * 8 + wave) * 8 + lr) * (unsigned)g.ldx + (unsigned)(cl * 8)) * 2u;
+  // one base offset per operand; the per-instruction offsets are scalar multiples added at the point of use (the
+  // kernel lives at the VGPR limit: keeping 4 + 4 hoisted copies spills, and a scratch reload drains the DMA queue)
+  const unsigned a_base = ((unsigned)((bimg * H + oy - 1) * W + ox0 + wave * 8 + lr) * (unsigned)g.ldx + (unsigned)(cl * 8)) * 2u;
+  const unsigned a_qstep = 64u * (unsigned)g.ldx * 2u;  // 64 slab rows further
   // halo: lanes 0, 1 of wave w carry chunks 2w, 2w+1 of the 16 halo chunks (row 256: pixel ox0-1, row 257: ox0+256)
   const int hc = wave * 2 + (lane & 1);
   const int hrow = hc >> 3;
@@ -449,14 +449,10 @@ __global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __
   const int hpix = hrow == 0 ? ox0 - 1 : ox0 + BM;
   const bool h_ok = (unsigned)hpix < (unsigned)W;
   const unsigned h_off = ((unsigned)((bimg * H + oy - 1) * W + hpix) * (unsigned)g.ldx + (unsigned)(hcl * 8)) * 2u;
-  unsigned b_off[NBQ];
-  bool b_ok[NBQ];
-#pragma unroll
-  for (int q = 0; q < NBQ; ++q) {
-    const int r = (q * 8 + wave) * 8 + lr;
-    b_ok[q] = r < BN && n0 + r < n_end;
-    b_off[q] = ((unsigned)(n0 + r) * (unsigned)K + (unsigned)(cl * 8)) * 2u;
-  }
+  const int b_row = wave * 8 + lr;                       // row of this lane in its first weight instruction
+  const int b_rows = (n_end - n0 < BN) ? n_end - n0 : BN;  // valid rows of the weight tile
+  const unsigned b_base = ((unsigned)(n0 + b_row) * (unsigned)K + (unsigned)(cl * 8)) * 2u;
+  const unsigned b_qstep = 64u * (unsigned)K * 2u;
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)x, (short)0, (int)a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)Bw, (short)0, (int)b_bytes, 0x00020000);
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -468,17 +464,19 @@ __global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __
     bf16_t* dst = lds + sb * SLAB;
     if (part < 2) {
       const bool ok = row_ok && cb * 64 + cl * 8 < Cp;
+      unsigned base = a_base;
+      asm volatile("" : "+v"(base));  // opaque: recomputed per use, never hoisted
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq) {
         const int q = part * 2 + qq;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr)(dst + (q * 8 + wave) * 512), 16,
-                                                 ok ? a_off[q] + step_off : OOB, 0, 0, 0);
+        const unsigned voff = ok ? base + (unsigned)q * a_qstep + step_off : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr)(dst + (q * 8 + wave) * 512), 16, voff, 0, 0, 0);
       }
     } else {
       const bool ok = row_ok && h_ok && cb * 64 + hcl * 8 < Cp;
+      const unsigned voff = ok ? h_off + step_off : OOB;
       if (lane < 2)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr)(dst + 256 * BK + wave * 16), 16,
-                                                 ok ? h_off + step_off : OOB, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr)(dst + 256 * BK + wave * 16), 16, voff, 0, 0, 0);
     }
   };
   // weight tile of (ky, kx, cb) -> ring slot
@@ -486,10 +484,12 @@ __global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __
     const unsigned step_off = ((unsigned)((ky * 3 + kx) * Cp) + (unsigned)cb * 64u) * 2u;
     const bool c_ok = cb * 64 + cl * 8 < Cp;
     bf16_t* dst = lds + 2 * SLAB + slot * BT;
+    unsigned base = b_base;
+    asm volatile("" : "+v"(base));
 #pragma unroll
     for (int q = 0; q < NBQ; ++q) {
       if (RAG != 0 && q == NBQ - 1 && wave >= RAG) break;  // wave-uniform
-      const unsigned voff = (c_ok && b_ok[q]) ? b_off[q] + step_off : OOB;
+      const unsigned voff = (c_ok && q * 64 + b_row < b_rows) ? base + (unsigned)q * b_qstep + step_off : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr)(dst + (q * 8 + wave) * 512), 16, voff, 0, 0, 0);
     }
   };
@@ -513,55 +513,88 @@ __global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __
 
   const int frow = lane & 15;
   const int fchunk = lane >> 4;
+  // Two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run half a sub-step apart: every sub-step is a READ
+  // phase (issue the LDS-DMA, fetch both K halves of the fragments) and an MFMA phase (48-56 back-to-back MFMAs), each
+  // closed by a barrier; group 1 starts one barrier late, so on every SIMD one wave feeds the matrix core while the
+  // other one reads.  Buffer life times with the lag (intervals between barriers, sub-step j: group 0 reads in interval
+  // 2j, group 1 in 2j+1): tile j's slot is re-filled from interval 2j+2 on; a share issued in READ(j-1) is retired by
+  // group 1 at the end of READ(j) and by group 0 at the end of MFMA(j), both in front of the barrier that ends interval
+  // 2j+1, i.e. before the first read of tile j+1 in interval 2j+2.
+  const int grp = wave >> 2;
+  if (grp == 1) __builtin_amdgcn_s_barrier();
   int ky = 0, cb = 0;
-  for (int s = 0; s < NS; ++s) {
-    const int sb = s & 1;
+  // one step = (ky, cb) with its three kx sub-steps; the slab parity is a compile-time constant (two steps per loop
+  // trip) so that every LDS address is a per-lane base plus an immediate
+  auto step = [&](auto sbc, int s) {
+    constexpr int sb = decltype(sbc)::value;
     const bool more = s + 1 < NS;
     int ky1 = ky, cb1 = cb + 1;
     if (cb1 == NCB) { cb1 = 0; ky1 = ky + 1; }
     const bf16_t* As = lds + sb * SLAB;
     auto sub = [&](auto kxc) {
       constexpr int kx = decltype(kxc)::value;
-      // issue: share of the next slab, weight tile two sub-steps ahead
-      if (more) {
-        if constexpr (kx == 0) { issue_a(0, ky1, cb1, sb ^ 1); issue_a(2, ky1, cb1, sb ^ 1); }
-        if constexpr (kx == 1) issue_a(1, ky1, cb1, sb ^ 1);
+      constexpr int NA = kx == 0 ? 3 : (kx == 1 ? 2 : 0);
+      auto retire = [&]() {  // all but this sub-step's own issues have landed
+        if constexpr ((ABL & 1) != 0) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (more) {
+          if (RAG != 0 && wave >= RAG) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NBQ - (RAG != 0 ? 1 : 0)) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NBQ) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      };
+      // ---- READ phase: share of the next slab, weight tile two sub-steps ahead, this sub-step's fragments
+      if constexpr ((ABL & 1) == 0) {
+        if (more) {
+          if constexpr (kx == 0) { issue_a(0, ky1, cb1, sb ^ 1); issue_a(2, ky1, cb1, sb ^ 1); }
+          if constexpr (kx == 1) issue_a(1, ky1, cb1, sb ^ 1);
+        }
+        if constexpr (kx == 0) issue_b(ky, 2, cb, 2);
+        else if (more) issue_b(ky1, kx - 1, cb1, kx - 1);
       }
-      if constexpr (kx == 0) issue_b(ky, 2, cb, 2);
-      else if (more) issue_b(ky1, kx - 1, cb1, kx - 1);
       const bf16_t* Bs = lds + 2 * SLAB + kx * BT;
+      bf16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        bf16x8 fa[TM], fb[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int r = wm * 64 + i * 16 + frow;      // tile pixel
           int sr = r + kx - 1;                         // slab row of the tap's pixel
           if (kx == 0 && i == 0) sr = (sr < 0) ? 256 : sr;
           if (kx == 2 && i == TM - 1) sr = (sr > 255) ? 257 : sr;
-          fa[i] = *reinterpret_cast<const bf16x8*>(As + swz_off(sr, h * 4 + fchunk));
+          fa[h][i] = *reinterpret_cast<const bf16x8*>(As + swz_off(sr, h * 4 + fchunk));
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          fb[j] = *reinterpret_cast<const bf16x8*>(Bs + swz_off(wn * TN * 16 + j * 16 + frow, h * 4 + fchunk));
+          fb[h][j] = *reinterpret_cast<const bf16x8*>(Bs + swz_off(wn * TN * 16 + j * 16 + frow, h * 4 + fchunk));
+      }
+      if (grp == 1) retire();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr ((ABL & 4) == 0) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // ---- MFMA phase
+      if constexpr ((ABL & 16) != 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[h][i]));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[h][j]));
+        }
+      } else {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[h][j], fa[h][i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
       }
-      // everything issued before this sub-step has landed (own share); the barrier makes that true for every wave's
-      constexpr int NA = kx == 0 ? 3 : (kx == 1 ? 2 : 0);
-      if (more) {
-        if (RAG != 0 && wave >= RAG) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NBQ - (RAG != 0 ? 1 : 0)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NBQ) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if (grp == 0) retire();
+      if constexpr ((ABL & 4) == 0) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     };
     sub(std::integral_constant<int, 0>{});
@@ -569,7 +602,14 @@ __global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __
     sub(std::integral_constant<int, 2>{});
     ky = ky1;
     cb = cb1;
+  };
+  int s = 0;
+  for (; s + 1 < NS; s += 2) {
+    step(std::integral_constant<int, 0>{}, s);
+    step(std::integral_constant<int, 1>{}, s + 1);
   }
+  if (s < NS) step(std::integral_constant<int, 0>{}, s);
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // group 1's last MFMA phase: every wave passes the same number of barriers
   nt_epilogue<WM, WN, TM, TN, HEAD>(acc, reinterpret_cast<float*>(lds), e, tile_n, m0, M, n0, n_end, tid);
 }
 
