@@ -545,14 +545,6 @@ __global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __
         }
       };
       // ---- READ phase: share of the next slab, weight tile two sub-steps ahead, this sub-step's fragments
-      if constexpr ((ABL & 1) == 0) {
-        if (more) {
-          if constexpr (kx == 0) { issue_a(0, ky1, cb1, sb ^ 1); issue_a(2, ky1, cb1, sb ^ 1); }
-          if constexpr (kx == 1) issue_a(1, ky1, cb1, sb ^ 1);
-        }
-        if constexpr (kx == 0) issue_b(ky, 2, cb, 2);
-        else if (more) issue_b(ky1, kx - 1, cb1, kx - 1);
-      }
       const bf16_t* Bs = lds + 2 * SLAB + kx * BT;
       bf16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
@@ -568,6 +560,15 @@ __global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           fb[h][j] = *reinterpret_cast<const bf16x8*>(Bs + swz_off(wn * TN * 16 + j * 16 + frow, h * 4 + fchunk));
+      }
+      asm volatile("" ::: "memory");  // fragment reads first: their latency hides behind the DMA issue
+      if constexpr ((ABL & 1) == 0) {
+        if (more) {
+          if constexpr (kx == 0) { issue_a(0, ky1, cb1, sb ^ 1); issue_a(2, ky1, cb1, sb ^ 1); }
+          if constexpr (kx == 1) issue_a(1, ky1, cb1, sb ^ 1);
+        }
+        if constexpr (kx == 0) issue_b(ky, 2, cb, 2);
+        else if (more) issue_b(ky1, kx - 1, cb1, kx - 1);
       }
       if (grp == 1) retire();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
