@@ -80,6 +80,9 @@ CONV_CASES = [
     # rows of whole 256-pixel tiles, M >= 16384: the 3x3 row-slab kernel (fwd and dgrad), channel-block tails, both halos
     (2, 72, 33, 256, 200, 3, 1, 1),
     (1, 64, 34, 512, 384, 3, 1, 1),
+    # ... and M >= 65536 with >= 128 input channels: the wgrad row-slab kernel (n / channel tails, W = 64 and 192)
+    (2, 136, 512, 64, 200, 3, 1, 1),
+    (1, 384, 342, 192, 136, 3, 1, 1),
 ]
 
 

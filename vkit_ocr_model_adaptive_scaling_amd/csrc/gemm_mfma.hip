@@ -843,6 +843,251 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Weight gradient of the same row-aligned 3x3 / stride 1 / pad 1 convolutions (rows a multiple of 64 pixels):
+//   gw[n][ky][kx][c] += sum over the block's pixels of dy[pixel][n] * x[pixel + (ky-1, kx-1)][c].
+// A block owns 128 output channels x (3 kx taps x 128 input channels) for ONE ky and walks its pixel split 64 pixels
+// (a piece of one image row) at a time: the 66-pixel x slab of input row oy+ky-1 serves the three kx taps as
+// row-shifted transposing reads, so a chunk stages 16 KB of dy + 17 KB of x for 2*64*128*384 flops (the generic TN
+// kernel: 61 KB for 2*64*224*256).  Staging is LDS-DMA into a ring of 4 chunk buffers (2 chunks in flight behind
+// the one being read); both operands stay [pixel][channel] with 256-byte rows, the 32-byte block index XOR-ed with
+// (row & 7) - applied to the DMA source chunk and to the reads - so the 8 rows a half-wave touches in one
+// ds_read_b64_tr_b16 sit on distinct banks.  8 waves: every wave holds all 8 n tiles x 3 of the 24 K-column tiles.
+// Same two-group READ / MFMA phase schedule as conv3x3_slab_mfma_kernel (chunk t: group 0 reads in interval 2t,
+// group 1 in 2t+1; its buffer is re-filled from interval 2t+2 on; a wave's issues for chunk t+3 happen in its
+// READ(t) phase and are retired - all but the two youngest chunks' worth - in front of the barrier ending interval
+// 2t+1, while chunk t+1 is first read in interval 2t+2).
+constexpr int WG_ROWS = 64, WG_N = 128, WG_C = 128;
+constexpr int WG_DY = WG_ROWS * WG_N;           // elements
+constexpr int WG_X = 68 * WG_C;                 // rows 0..63 pixels, 64 / 65 left / right halo, 66 / 67 unused
+constexpr int WG_BUF = WG_DY + WG_X;
+
+typedef s16x4 __attribute__((address_space(3))) * wg_lds_ptr;
+// k-permuted transposed fragment (see tr_frag) from two byte addresses inside the LDS window: elements 0..3 <- a0,
+// elements 4..7 <- a1 (16 rows further)
+__device__ __forceinline__ bf16x8 wg_frag2(unsigned a0, unsigned a1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_ptr)(uintptr_t)a0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_ptr)(uintptr_t)a1);
+  union { struct { s16x4 l, h; } s; bf16x8 v; } u;
+  u.s.l = lo;
+  u.s.h = hi;
+  return u.v;
+}
+
+__global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
+                                                                 const bf16_t* __restrict__ dy, long lddy, int Np,
+                                                                 long M, int K, int chunks_per_split,
+                                                                 float* __restrict__ gw, float* __restrict__ gb,
+                                                                 unsigned x_bytes, unsigned dy_bytes) {
+  constexpr int TNn = 8, TK = 3;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  __shared__ __attribute__((aligned(1024))) bf16_t lds[4 * WG_BUF];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = g.Hin, W = g.Win, Cp = g.Cp;
+  // work order: as in gemm_tn_mfma_kernel (contiguous runs per XCD, all tiles of one pixel split before the next)
+  const unsigned ntn = (unsigned)((Np + WG_N - 1) / WG_N), ncb = (unsigned)((Cp + WG_C - 1) / WG_C);
+  const unsigned tiles = ntn * 3u * ncb;
+  const unsigned total = gridDim.x;
+  const unsigned xcd = blockIdx.x & 7u, slot8 = blockIdx.x >> 3;
+  const unsigned q8 = total >> 3, r8 = total & 7u;
+  const unsigned work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
+  const unsigned tile = work % tiles;
+  const int n0 = (int)(tile % ntn) * WG_N;
+  const int ky = (int)((tile / ntn) % 3u);
+  const int cb = (int)(tile / (ntn * 3u));
+  const long total_chunks = M / WG_ROWS;
+  const long c_beg = (long)(work / tiles) * chunks_per_split;
+  const int nchunks = (int)((c_beg + chunks_per_split <= total_chunks ? chunks_per_split : total_chunks - c_beg));
+
+  // DMA roles.  A wave instruction fills 4 rows x 16 chunk positions (1 KB); wave w takes instructions w and w + 8 of
+  // the 16 of each operand: rows 4w + (lane>>4) and 32 + 4w + (lane>>4).  Position c' of row r holds logical 16-byte
+  // chunk (((c'>>1) ^ (r & 7)) << 1) | (c' & 1); r & 7 = 4*(w&1) + (lane>>4) for both instructions.
+  const int lrow = lane >> 4, cpos = lane & 15;
+  const int rkey = 4 * (wave & 1) + lrow;
+  const int lchunk = (((cpos >> 1) ^ rkey) << 1) | (cpos & 1);
+  const bool d_ok = n0 + lchunk * 8 < Np;
+  const bool x_ok = cb * WG_C + lchunk * 8 < Cp;
+  const unsigned d_lane = (unsigned)((4 * wave + lrow) * lddy + n0 + lchunk * 8) * 2u;   // + chunk pixel base
+  const unsigned x_lane = (unsigned)((4 * wave + lrow) * g.ldx + cb * WG_C + lchunk * 8) * 2u;
+  // halo: lanes 0..3 of wave w carry positions 4w .. 4w+3 of the 32 halo chunks (row 64: pixel -1, row 65: pixel 64)
+  const int hc = wave * 4 + (lane & 3);
+  const int hrow = hc >> 4;
+  const int hpos = hc & 15;
+  const int hl = (((hpos >> 1) ^ hrow) << 1) | (hpos & 1);   // (64 + hrow) & 7 = hrow
+  const bool hx_ok = cb * WG_C + hl * 8 < Cp;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, (short)0, (int)x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)dy, (short)0, (int)dy_bytes, 0x00020000);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  // issue cursor: chunk -> (image, row, first pixel); 64 | W keeps a chunk inside one image row
+  long ic = c_beg;
+  int i_b, i_y, i_x;
+  {
+    const long pix = c_beg * WG_ROWS;
+    const int hw = H * W;
+    i_b = (int)(pix / hw);
+    const int rem = (int)(pix - (long)i_b * hw);
+    i_y = rem / W;
+    i_x = rem - i_y * W;
+  }
+  auto issue_chunk = [&](int buf) {  // 5 instructions per wave
+    bf16_t* Ds = lds + buf * WG_BUF;
+    bf16_t* Xs = Ds + WG_DY;
+    const unsigned d_base = (unsigned)(ic * WG_ROWS * lddy) * 2u;
+    const int iy = i_y + ky - 1;
+    const bool row_ok = (unsigned)iy < (unsigned)H;
+    const unsigned x_base = (unsigned)(((i_b * H + iy) * W + i_x) * g.ldx) * 2u;
+    unsigned dl = d_lane, xl = x_lane;
+    asm volatile("" : "+v"(dl), "+v"(xl));
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const unsigned vd = d_ok ? d_base + dl + (unsigned)(q * 32 * lddy * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lds_ptr)(Ds + (q * 8 + wave) * 512), 16, vd, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const unsigned vx = (row_ok && x_ok) ? x_base + xl + (unsigned)(q * 32 * g.ldx * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(Xs + (q * 8 + wave) * 512), 16, vx, 0, 0, 0);
+    }
+    {
+      const int hpix = hrow == 0 ? i_x - 1 : i_x + WG_ROWS;
+      const bool ok = row_ok && hx_ok && (unsigned)hpix < (unsigned)W;
+      const unsigned vh = ok ? (unsigned)(((i_b * H + iy) * W + hpix) * g.ldx + cb * WG_C + hl * 8) * 2u : OOB;
+      if (lane < 4)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(Xs + 64 * WG_C + wave * 32), 16, vh, 0, 0, 0);
+    }
+    ++ic;
+    i_x += WG_ROWS;
+    if (i_x == W) {
+      i_x = 0;
+      if (++i_y == H) { i_y = 0; ++i_b; }
+    }
+  };
+
+  f32x4 acc[TNn][TK];
+#pragma unroll
+  for (int i = 0; i < TNn; ++i)
+#pragma unroll
+    for (int j = 0; j < TK; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // bias gradient = column sums of dy: wave 0 of the (ky = 0, cb = 0) blocks adds up the dy fragments it holds anyway
+  const bool do_bias = gb != nullptr && ky == 0 && cb == 0 && wave == 0;
+  float bsum[TNn];
+#pragma unroll
+  for (int i = 0; i < TNn; ++i) bsum[i] = 0.f;
+  // this wave's K-column tiles: columns wave*48 + 16 j of [kx][128 channels]
+  int x_shift[TK], x_blk[TK];
+#pragma unroll
+  for (int j = 0; j < TK; ++j) {
+    const int col = wave * 48 + j * 16;
+    x_shift[j] = (col >> 7) - 1;
+    x_blk[j] = (col & 127) >> 4;
+  }
+  // Fragment addresses (bytes from the start of a chunk buffer) of the (K half 0, rows +0) read; the other three reads
+  // of a fragment are +4096 (16 rows) / +8192 (K half 1): the XOR key (row & 7) is the same for all four.  The x slab
+  // is read row-shifted by kx - 1: only pixel -1 (half 0, first read, shift -1) and pixel 64 (half 1, second read,
+  // shift +1) leave the pattern and go to the halo rows 64 / 65.
+  const int fr = 4 * (lane >> 4) + ((lane & 15) >> 2);  // row of this lane inside a 16-row group
+  const int fp = (lane & 3) * 8;                         // byte offset of its 4 columns inside the 32-byte block
+  unsigned d_addr[TNn], x_addr[TK], x_first[TK], x_last[TK];
+#pragma unroll
+  for (int i = 0; i < TNn; ++i) d_addr[i] = (unsigned)(fr * 256 + ((i ^ (fr & 7)) << 5) + fp);
+#pragma unroll
+  for (int j = 0; j < TK; ++j) {
+    const int r = fr + x_shift[j];
+    x_addr[j] = (unsigned)(WG_DY * 2 + r * 256 + ((x_blk[j] ^ (r & 7)) << 5) + fp);
+    x_first[j] = r < 0 ? (unsigned)(WG_DY * 2 + 64 * 256 + ((x_blk[j] ^ 0) << 5) + fp) : x_addr[j];
+    x_last[j] = r + 48 > 63 ? (unsigned)(WG_DY * 2 + 65 * 256 + ((x_blk[j] ^ 1) << 5) + fp) : x_addr[j] + 12288u;
+  }
+  const unsigned lds_base = (unsigned)(uintptr_t)(wg_lds_ptr)lds;
+
+  const int grp = wave >> 2;
+  if (nchunks > 0) issue_chunk(0);
+  if (nchunks > 1) issue_chunk(1);
+  if (nchunks > 2) issue_chunk(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  for (int t = 0; t < nchunks; ++t) {
+    const unsigned bufb = lds_base + (unsigned)((t & 3) * WG_BUF * 2);
+    // ---- READ phase
+    bf16x8 fd[2][TNn], fx[2][TK];
+#pragma unroll
+    for (int i = 0; i < TNn; ++i) {
+      const unsigned a = bufb + d_addr[i];
+      fd[0][i] = wg_frag2(a, a + 4096u);
+      fd[1][i] = wg_frag2(a + 8192u, a + 12288u);
+    }
+#pragma unroll
+    for (int j = 0; j < TK; ++j) {
+      const unsigned a = bufb + x_addr[j];
+      fx[0][j] = wg_frag2(bufb + x_first[j], a + 4096u);
+      fx[1][j] = wg_frag2(a + 8192u, bufb + x_last[j]);
+    }
+    asm volatile("" ::: "memory");
+    const bool issued = t + 3 < nchunks;
+    if (issued) issue_chunk((t + 3) & 3);
+    // chunks t+2 and t+3 (10 instructions) may stay in flight; near the end of the split fewer were issued
+    auto retire = [&]() {
+      if (t + 3 < nchunks) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (grp == 1) retire();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // ---- MFMA phase
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < TNn; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[h][i], fx[h][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    if (do_bias) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < TNn; ++i)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) bsum[i] += (float)fd[h][i][q];
+    }
+    if (grp == 0) retire();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // group 1's last MFMA phase: every wave passes the same number of barriers
+
+  // D[row = n_local][col = k_local]: lane holds col = lane&15, rows (lane>>4)*4 + r
+#pragma unroll
+  for (int j = 0; j < TK; ++j) {
+    const int c = cb * WG_C + x_blk[j] * 16 + (lane & 15);
+    if (c >= Cp) continue;
+    const long kk = (long)(ky * 3 + x_shift[j] + 1) * Cp + c;
+#pragma unroll
+    for (int i = 0; i < TNn; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + i * 16 + (lane >> 4) * 4 + r;
+        if (n < Np) atomicAdd(gw + (long)n * K + kk, acc[i][j][r]);
+      }
+    }
+  }
+  if (do_bias) {  // lanes l, l^16, l^32, l^48 hold different rows of the same column
+#pragma unroll
+    for (int i = 0; i < TNn; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int n = n0 + i * 16 + (lane & 15);
+      if (lane < 16 && n < Np) atomicAdd(gb + n, v);
+    }
+  }
+}
+
 }  // namespace
 
 template <int WM, int WN, int TM, int TN>
@@ -1003,6 +1248,29 @@ int vkas_gemm_tn_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* d
   const long M = (long)g->B * g->Hout * g->Wout;
   const int K = g->KH * g->KW * g->Cp;
   if (M == 0) return VKAS_OK;
+  // row-aligned 3x3 / stride 1 / pad 1 with wide operands: the slab kernel
+  static const bool no_slab = getenv("VKAS_TN_NOSLAB") != nullptr;
+  const long x_bytes = (((long)g->B * g->Hin * g->Win - 1) * g->ldx + g->Cp) * 2;
+  const long dy_bytes = ((M - 1) * lddy + Np) * 2;
+  if (!no_slab && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1 && g->Hout == g->Hin && g->Wout == g->Win &&
+      g->Win % 64 == 0 && M >= 65536 && Np >= 112 && g->Cp >= 128 && x_bytes < 0xFFFFFFF0L && dy_bytes < 0xFFFFFFF0L) {
+    const long tiles = vkas_cdiv(Np, 128) * 3 * vkas_cdiv(g->Cp, 128);
+    const long chunks = M / 64;
+    // Pixel splits: whole splits per XCD (multiple of 8).  The tiles of one split walk the same dy / x chunks at the same
+    // time and share them through that XCD's L2 (every operand byte is used by 9 tiles): keeping a split's tiles
+    // together matters more than filling the last round of workgroups (a round-balanced, XCD-straddling split count
+    // measured 5% slower).  About 3 rounds of the 256 resident workgroups, at least 16 chunks per split.
+    long splits = vkas_cdiv(3 * 256, tiles);
+    splits = vkas_cdiv(splits, 8) * 8;
+    if (splits > chunks / 16) splits = chunks / 16 > 0 ? chunks / 16 : 1;
+    const long cps = vkas_cdiv(chunks, splits);
+    splits = vkas_cdiv(chunks, cps);
+    conv3x3_wgrad_slab_kernel<<<(unsigned)(tiles * splits), 512, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy, Np, M, K,
+                                                                          (int)cps, gw, gb, (unsigned)x_bytes,
+                                                                          (unsigned)dy_bytes);
+    VKAS_LAUNCH_CHECK("conv3x3_wgrad_slab");
+    return VKAS_OK;
+  }
   const int bn = vkas_gemm_tn_tile_choice(M, Np, K);
   if (bn == 224) launch_tn<2, 4, 7, 4>(x, g, dy, lddy, Np, M, K, gw, gb, st);
   else if (bn == 192) launch_tn<2, 4, 6, 4>(x, g, dy, lddy, Np, M, K, gw, gb, st);
