@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--shape', default='8,512,512,384,384,3')
 ap.add_argument('--rounds', type=int, default=5)
 ap.add_argument('--iters', type=int, default=3)
+ap.add_argument('--mode', type=int, default=0, help='0 plain store, 1 GELU dual store')
 ap.add_argument('libs', nargs='+')
 args = ap.parse_args()
 B, H, W, C, N, KH = map(int, args.shape.split(','))
@@ -25,7 +26,10 @@ Bw = (torch.randn((N, KH * KH * C), generator=g, device='cuda') * 0.02).bfloat16
 out = torch.empty((B, H, W, N), device='cuda', dtype=torch.bfloat16)
 geom = _lib.ConvGeom(B, H, W, H, W, C, C, KH, KH, 1, KH // 2)
 epi = _lib.Epilogue()
-epi.mode, epi.out, epi.ldo = _lib.EPI_NONE, out.data_ptr(), N
+epi.mode, epi.out, epi.ldo = args.mode, out.data_ptr(), N
+out2 = torch.empty_like(out)
+if args.mode == 1:
+    epi.out2, epi.ldo2 = out2.data_ptr(), N
 libs = []
 for p in args.libs:
     L = ctypes.CDLL(os.path.abspath(p))

@@ -110,7 +110,8 @@ __device__ __forceinline__ float dgelu_f(float x) {
 __device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& pdf_x) {
   const float ax = fabsf(x);
   const float e = __expf(-0.5f * x * x);
-  const float t = __frcp_rn(fmaf(0.2316418881f, ax, 1.0f));  // 1 / (1 + p*|x|/sqrt2), p = 0.3275911
+  // 1 / (1 + p*|x|/sqrt2), p = 0.3275911: v_rcp_f32 (1 ulp), not the ~10-instruction IEEE division sequence
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.2316418881f, ax, 1.0f));
   const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
   const float half_erfc = 0.5f * poly * e;                    // 0.5 * erfc(|x|/sqrt2)
   cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
