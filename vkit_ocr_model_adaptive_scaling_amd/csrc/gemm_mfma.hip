@@ -115,48 +115,70 @@ __device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head,
   }
 }
 
-// Epilogue shared by the NT kernels: the accumulators (lane = 4 consecutive channels of one pixel) go through LDS one
-// wave-row at a time so that every global access of the fused epilogue is a coalesced 16-byte piece of an output row.
-// `stage` is the kernel's (idle) tile storage; the caller guarantees that every wave has finished reading it.
+// Epilogue shared by the NT kernels.  `stage` is the kernel's (idle) tile storage; the caller guarantees that every wave
+// has finished reading it.  The accumulators (lane = 4 consecutive channels of one pixel) go through LDS so that every
+// global access of the fused epilogue is a coalesced 16-byte piece of an output row.
+//  * plain modes: ONE pass for the whole tile.  Every wave adds the bias and writes bf16(acc + bias) - exactly the value
+//    the layer's output tensor holds, and what the reference's bf16 autocast feeds to GELU / the residual / the GELU
+//    backward - so the whole 256 x BN tile fits the tile buffers, all waves stage at once and there is one barrier
+//    instead of eight (the 4-pass fp32 staging was ~40% of a tile's time on the short-K, HBM-bound layer GEMMs).
+//  * fused head tail: fp32 staging, one wave-row (TM*16 rows) per pass: LayerNorm statistics want the fp32 sums.
 template <int WM, int WN, int TM, int TN, bool HEAD>
 __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[TM][TN], float* stage, const vkas_epilogue& e, int tile_n,
                                             long m0, long M, int n0, int n_end, int tid) {
   constexpr int NTHR = WM * WN * 64;
-  constexpr int BN = WN * TN * 16;
-  constexpr int EP = BN + 4;            // fp32 row pitch: pitch % 32 == 4 keeps the 16-byte writes conflict free
-  constexpr int ER = TM * 16;           // rows per pass
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int VPR = BN / 8;           // 8-channel vectors per row
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-#pragma unroll 1
-  for (int pass = 0; pass < WM; ++pass) {
-    if (wm == pass) {
+  if constexpr (!HEAD) {
+    constexpr int PB = BN * 2 + 16;     // staged row pitch in bytes (16-byte aligned rows, 2-way at worst on the b64 writes)
+    static_assert(BM * PB <= 2 * (BM + BN) * BK * 2, "single-pass staging must fit the tile buffers");
+    char* st = reinterpret_cast<char*>(stage);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j) {
+      const int cl = wn * TN * 16 + j * 16 + (lane >> 4) * 4;   // column inside the tile
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e.bias && n0 + cl < n_end) b = *reinterpret_cast<const float4*>(e.bias + n0 + cl);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          *reinterpret_cast<f32x4*>(stage + (i * 16 + (lane & 15)) * EP + wn * TN * 16 + j * 16 + (lane >> 4) * 4) =
-              acc[i][j];
-    }
-    __syncthreads();
-    if constexpr (HEAD) {
-      head_tail_rows<NTHR, ER, EP, VPR>(e, tile_n, stage, m0 + (long)pass * ER, M, n0, n_end - n0, tid);
-    } else {
-      for (int t = tid; t < ER * VPR; t += NTHR) {
-        const int row = t / VPR, c8 = t - row * VPR;
-        const long m = m0 + pass * ER + row;
-        const int n = n0 + c8 * 8;
-        if (m < M && n < n_end) {
-          float v[8];
-          const float4 lo = *reinterpret_cast<const float4*>(stage + row * EP + c8 * 8);
-          const float4 hi = *reinterpret_cast<const float4*>(stage + row * EP + c8 * 8 + 4);
-          v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-          epi_store8<bf16_t>(e, m, n, v);
-        }
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * TM * 16 + i * 16 + (lane & 15);
+        float v[4] = {acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w};
+        store4(reinterpret_cast<bf16_t*>(st + row * PB) + cl, v);
       }
     }
     __syncthreads();
+    vkas_epilogue e2 = e;
+    e2.bias = nullptr;  // already added
+#pragma unroll 2
+    for (int t = tid; t < BM * VPR; t += NTHR) {
+      const int row = t / VPR, c8 = t - row * VPR;
+      const long m = m0 + row;
+      const int n = n0 + c8 * 8;
+      if (m < M && n < n_end) {
+        float v[8];
+        load8(reinterpret_cast<const bf16_t*>(st + row * PB) + c8 * 8, v);
+        epi_store8<bf16_t>(e2, m, n, v);
+      }
+    }
+  } else {
+    constexpr int EP = BN + 4;            // fp32 row pitch: pitch % 32 == 4 keeps the 16-byte writes conflict free
+    constexpr int ER = TM * 16;           // rows per pass
+#pragma unroll 1
+    for (int pass = 0; pass < WM; ++pass) {
+      if (wm == pass) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            *reinterpret_cast<f32x4*>(stage + (i * 16 + (lane & 15)) * EP + wn * TN * 16 + j * 16 + (lane >> 4) * 4) =
+                acc[i][j];
+      }
+      __syncthreads();
+      head_tail_rows<NTHR, ER, EP, VPR>(e, tile_n, stage, m0 + (long)pass * ER, M, n0, n_end - n0, tid);
+      __syncthreads();
+    }
   }
 }
 
@@ -399,33 +421,33 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
 //    share of the next slab, then waits with a counted vmcnt (only this sub-step's own issues stay in flight) in
 //    front of a raw s_barrier.  A staged buffer is read only after the barrier that follows the wait retiring it,
 //    and re-filled only after the barrier that ends its last reading sub-step.
-template <int TN, bool HEAD>
-__global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
-                                                                const bf16_t* __restrict__ Bw, int Np, long M, int K,
-                                                                vkas_epilogue e, unsigned a_bytes, unsigned b_bytes) {
+constexpr int SLAB = 264 * BK;  // rows 0..255 tile pixels, 256 / 257 left / right halo, 258..263 unused
+
+// TN = MFMA column tiles per wave (block N extent 32 * TN); BNT = N extent the launch spaces its N tiles by (>= 32 * TN:
+// a fused-head launch sized for its widest head runs the narrower heads with a smaller TN, see the kernel below).
+typedef __attribute__((address_space(3))) bf16_t lds_bf16;
+typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
+
+template <int TN, bool HEAD, int BNT>
+__device__ __forceinline__ void conv3x3_slab_body(const bf16_t* __restrict__ x, const vkas_conv_geom& g,
+                                                  const bf16_t* __restrict__ Bw, int Np, long M, int K,
+                                                  const vkas_epilogue& e, unsigned a_bytes, unsigned b_bytes,
+                                                  lds_bf16* lds, unsigned tile, unsigned ntile_n) {
   constexpr int WM = 4, WN = 2, TM = 4;
   constexpr int BM = 256, BN = WN * TN * 16;
-  constexpr int SLAB = 264 * BK;             // rows 0..255 tile pixels, 256 / 257 left / right halo, 258..263 unused
   constexpr int BT = BN * BK;
   constexpr int NWI = BN / 8;                // wave instructions (8 rows each) per weight tile
   constexpr int NBQ = (NWI + 7) / 8;         // ... per wave (waves >= RAG issue one less when NWI % 8 != 0)
   constexpr int RAG = NWI % 8;
   constexpr unsigned OOB = 0xFFFFFFF0u;
-  __shared__ __attribute__((aligned(1024))) bf16_t lds[2 * SLAB + 3 * BT];
   static_assert(TM * 16 * (BN + 4) * 4 <= (2 * SLAB + 3 * BT) * 2, "epilogue staging must fit");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  // tile order: as in gemm_nt_mfma_kernel (contiguous runs per XCD, N tiles fastest)
-  const unsigned ntile_n = HEAD ? (unsigned)e.head.n_heads : (unsigned)((Np + BN - 1) / BN);
-  const unsigned total = gridDim.x;
-  const unsigned xcd = blockIdx.x & 7u, slot8 = blockIdx.x >> 3;
-  const unsigned q8 = total >> 3, r8 = total & 7u;
-  const unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
   const long m0 = (long)(tile / ntile_n) * BM;
   const int tile_n = (int)(tile % ntile_n);
-  const int n0 = HEAD ? e.head.n0[tile_n] : tile_n * BN;
+  const int n0 = HEAD ? e.head.n0[tile_n] : tile_n * BNT;
   const int n_end = HEAD ? n0 + e.head.np[tile_n] : Np;
   const int H = g.Hin, W = g.Win, Cp = g.Cp;
   const int hw = H * W;
@@ -461,7 +483,7 @@ __global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __
   auto issue_a = [&](int part, int ky, int cb, int sb) {
     const bool row_ok = (unsigned)(oy - 1 + ky) < (unsigned)H;
     const unsigned step_off = (unsigned)ky * row_pitch + (unsigned)cb * 128u;
-    bf16_t* dst = lds + sb * SLAB;
+    lds_bf16* dst = lds + sb * SLAB;
     if (part < 2) {
       const bool ok = row_ok && cb * 64 + cl * 8 < Cp;
       unsigned base = a_base;
@@ -483,7 +505,7 @@ __global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __
   auto issue_b = [&](int ky, int kx, int cb, int slot) {
     const unsigned step_off = ((unsigned)((ky * 3 + kx) * Cp) + (unsigned)cb * 64u) * 2u;
     const bool c_ok = cb * 64 + cl * 8 < Cp;
-    bf16_t* dst = lds + 2 * SLAB + slot * BT;
+    lds_bf16* dst = lds + 2 * SLAB + slot * BT;
     unsigned base = b_base;
     asm volatile("" : "+v"(base));
 #pragma unroll
@@ -530,7 +552,7 @@ __global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __
     const bool more = s + 1 < NS;
     int ky1 = ky, cb1 = cb + 1;
     if (cb1 == NCB) { cb1 = 0; ky1 = ky + 1; }
-    const bf16_t* As = lds + sb * SLAB;
+    const lds_bf16* As = lds + sb * SLAB;
     auto sub = [&](auto kxc) {
       constexpr int kx = decltype(kxc)::value;
       constexpr int NA = kx == 0 ? 3 : (kx == 1 ? 2 : 0);
@@ -545,7 +567,7 @@ __global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __
         }
       };
       // ---- READ phase: share of the next slab, weight tile two sub-steps ahead, this sub-step's fragments
-      const bf16_t* Bs = lds + 2 * SLAB + kx * BT;
+      const lds_bf16* Bs = lds + 2 * SLAB + kx * BT;
       bf16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -555,11 +577,11 @@ __global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __
           int sr = r + kx - 1;                         // slab row of the tap's pixel
           if (kx == 0 && i == 0) sr = (sr < 0) ? 256 : sr;
           if (kx == 2 && i == TM - 1) sr = (sr > 255) ? 257 : sr;
-          fa[h][i] = *reinterpret_cast<const bf16x8*>(As + swz_off(sr, h * 4 + fchunk));
+          fa[h][i] = *(const lds_bf16x8*)(As + swz_off(sr, h * 4 + fchunk));
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          fb[h][j] = *reinterpret_cast<const bf16x8*>(Bs + swz_off(wn * TN * 16 + j * 16 + frow, h * 4 + fchunk));
+          fb[h][j] = *(const lds_bf16x8*)(Bs + swz_off(wn * TN * 16 + j * 16 + frow, h * 4 + fchunk));
       }
       asm volatile("" ::: "memory");  // fragment reads first: their latency hides behind the DMA issue
       if constexpr ((ABL & 1) == 0) {
@@ -611,7 +633,30 @@ __global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __
   }
   if (s < NS) step(std::integral_constant<int, 0>{}, s);
   if (grp == 0) __builtin_amdgcn_s_barrier();  // group 1's last MFMA phase: every wave passes the same number of barriers
-  nt_epilogue<WM, WN, TM, TN, HEAD>(acc, reinterpret_cast<float*>(lds), e, tile_n, m0, M, n0, n_end, tid);
+  nt_epilogue<WM, WN, TM, TN, HEAD>(acc, (float*)lds, e, tile_n, m0, M, n0, n_end, tid);
+}
+
+template <int TN, bool HEAD>
+__global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
+                                                                const bf16_t* __restrict__ Bw, int Np, long M, int K,
+                                                                vkas_epilogue e, unsigned a_bytes, unsigned b_bytes) {
+  constexpr int BN = 32 * TN;
+  __shared__ __attribute__((aligned(1024))) bf16_t lds[2 * SLAB + 3 * BN * BK];
+  // tile order: as in gemm_nt_mfma_kernel (contiguous runs per XCD, N tiles fastest)
+  const unsigned ntile_n = HEAD ? (unsigned)e.head.n_heads : (unsigned)((Np + BN - 1) / BN);
+  const unsigned total = gridDim.x;
+  const unsigned xcd = blockIdx.x & 7u, slot8 = blockIdx.x >> 3;
+  const unsigned q8 = total >> 3, r8 = total & 7u;
+  const unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
+  if constexpr (HEAD && TN == 7) {
+    // the launch is sized for its widest head (<= 224 columns); heads of <= 192 columns run the 6-tile body: 1/7 fewer
+    // MFMAs and weight bytes for three of the four precise heads
+    if (e.head.np[tile % ntile_n] <= 192) {
+      conv3x3_slab_body<6, true, BN>(x, g, Bw, Np, M, K, e, a_bytes, b_bytes, (lds_bf16*)lds, tile, ntile_n);
+      return;
+    }
+  }
+  conv3x3_slab_body<TN, HEAD, BN>(x, g, Bw, Np, M, K, e, a_bytes, b_bytes, (lds_bf16*)lds, tile, ntile_n);
 }
 
 // ---------------------------------------------------------------------------------------------------
