@@ -83,6 +83,7 @@ CONV_CASES = [
     # ... and M >= 65536 with >= 128 input channels: the wgrad row-slab kernel (n / channel tails, W = 64 and 192)
     (2, 136, 512, 64, 200, 3, 1, 1),
     (1, 384, 342, 192, 136, 3, 1, 1),
+    (1, 128, 256, 256, 256, 3, 1, 1),  # 128-channel n tiles (the two above pad less with 112)
 ]
 
 

@@ -919,12 +919,17 @@ __device__ __forceinline__ bf16x8 wg_frag2(unsigned a0, unsigned a1) {
   return u.v;
 }
 
+template <int TNn>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
                                                                  const bf16_t* __restrict__ dy, long lddy, int Np,
                                                                  long M, int K, int chunks_per_split,
                                                                  float* __restrict__ gw, float* __restrict__ gb,
                                                                  unsigned x_bytes, unsigned dy_bytes) {
-  constexpr int TNn = 8, TK = 3;
+  // TNn = 8: 128 output channels per block, dy rows of 256 B with the XOR swizzle.  TNn = 7: 112 channels, rows of
+  // 224 B = 56 banks - consecutive rows already start 8 banks apart, the image stays linear (N = 776: 7 tiles, 1% padding).
+  constexpr int TK = 3;
+  constexpr int BNn = TNn * 16, PD = BNn * 2;  // dy row pitch in bytes
+  constexpr int DWI = WG_ROWS * PD / 1024;     // dy wave instructions per chunk (16 or 14)
   constexpr unsigned OOB = 0xFFFFFFF0u;
   __shared__ __attribute__((aligned(1024))) bf16_t lds[4 * WG_BUF];
   const int tid = threadIdx.x;
@@ -932,14 +937,14 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const bf16_t* _
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = g.Hin, W = g.Win, Cp = g.Cp;
   // work order: as in gemm_tn_mfma_kernel (contiguous runs per XCD, all tiles of one pixel split before the next)
-  const unsigned ntn = (unsigned)((Np + WG_N - 1) / WG_N), ncb = (unsigned)((Cp + WG_C - 1) / WG_C);
+  const unsigned ntn = (unsigned)((Np + BNn - 1) / BNn), ncb = (unsigned)((Cp + WG_C - 1) / WG_C);
   const unsigned tiles = ntn * 3u * ncb;
   const unsigned total = gridDim.x;
   const unsigned xcd = blockIdx.x & 7u, slot8 = blockIdx.x >> 3;
   const unsigned q8 = total >> 3, r8 = total & 7u;
   const unsigned work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
   const unsigned tile = work % tiles;
-  const int n0 = (int)(tile % ntn) * WG_N;
+  const int n0 = (int)(tile % ntn) * BNn;
   const int ky = (int)((tile / ntn) % 3u);
   const int cb = (int)(tile / (ntn * 3u));
   const long total_chunks = M / WG_ROWS;
@@ -952,9 +957,26 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const bf16_t* _
   const int lrow = lane >> 4, cpos = lane & 15;
   const int rkey = 4 * (wave & 1) + lrow;
   const int lchunk = (((cpos >> 1) ^ rkey) << 1) | (cpos & 1);
-  const bool d_ok = n0 + lchunk * 8 < Np;
   const bool x_ok = cb * WG_C + lchunk * 8 < Cp;
-  const unsigned d_lane = (unsigned)((4 * wave + lrow) * lddy + n0 + lchunk * 8) * 2u;   // + chunk pixel base
+  // dy: instruction q of this wave is instruction w + 8q of the chunk; TNn = 8: row 4w + 32q + (lane>>4), swizzled chunk;
+  // TNn = 7: lane-linear over [64][14] chunks (instructions 14, 15 do not exist: waves 6, 7 issue one)
+  unsigned d_lane[2];
+  bool d_ok[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int row, c;
+    if constexpr (TNn == 8) {
+      row = 4 * wave + 32 * q + lrow;
+      c = lchunk;
+    } else {
+      const int ci = (wave + 8 * q) * 64 + lane;
+      row = ci / 14;
+      c = ci - row * 14;
+    }
+    d_ok[q] = n0 + c * 8 < Np && c * 8 < BNn;
+    d_lane[q] = (unsigned)(row * lddy + n0 + c * 8) * 2u;   // + chunk pixel base
+  }
+  const int d_count = (DWI == 16 || wave + 8 < DWI) ? 2 : 1;
   const unsigned x_lane = (unsigned)((4 * wave + lrow) * g.ldx + cb * WG_C + lchunk * 8) * 2u;
   // halo: lanes 0..3 of wave w carry positions 4w .. 4w+3 of the 32 halo chunks (row 64: pixel -1, row 65: pixel 64)
   const int hc = wave * 4 + (lane & 3);
@@ -983,11 +1005,12 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const bf16_t* _
     const int iy = i_y + ky - 1;
     const bool row_ok = (unsigned)iy < (unsigned)H;
     const unsigned x_base = (unsigned)(((i_b * H + iy) * W + i_x) * g.ldx) * 2u;
-    unsigned dl = d_lane, xl = x_lane;
-    asm volatile("" : "+v"(dl), "+v"(xl));
+    unsigned xl = x_lane;
+    asm volatile("" : "+v"(xl));
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const unsigned vd = d_ok ? d_base + dl + (unsigned)(q * 32 * lddy * 2) : OOB;
+      if (q == 1 && d_count == 1) break;  // wave-uniform
+      const unsigned vd = d_ok[q] ? d_base + d_lane[q] : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lds_ptr)(Ds + (q * 8 + wave) * 512), 16, vd, 0, 0, 0);
     }
 #pragma unroll
@@ -1036,7 +1059,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const bf16_t* _
   const int fp = (lane & 3) * 8;                         // byte offset of its 4 columns inside the 32-byte block
   unsigned d_addr[TNn], x_addr[TK], x_first[TK], x_last[TK];
 #pragma unroll
-  for (int i = 0; i < TNn; ++i) d_addr[i] = (unsigned)(fr * 256 + ((i ^ (fr & 7)) << 5) + fp);
+  for (int i = 0; i < TNn; ++i) d_addr[i] = (unsigned)(fr * PD + ((TNn == 8 ? (i ^ (fr & 7)) : i) << 5) + fp);
 #pragma unroll
   for (int j = 0; j < TK; ++j) {
     const int r = fr + x_shift[j];
@@ -1061,8 +1084,8 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const bf16_t* _
 #pragma unroll
     for (int i = 0; i < TNn; ++i) {
       const unsigned a = bufb + d_addr[i];
-      fd[0][i] = wg_frag2(a, a + 4096u);
-      fd[1][i] = wg_frag2(a + 8192u, a + 12288u);
+      fd[0][i] = wg_frag2(a, a + 16u * PD);
+      fd[1][i] = wg_frag2(a + 32u * PD, a + 48u * PD);
     }
 #pragma unroll
     for (int j = 0; j < TK; ++j) {
@@ -1073,10 +1096,12 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const bf16_t* _
     asm volatile("" ::: "memory");
     const bool issued = t + 3 < nchunks;
     if (issued) issue_chunk((t + 3) & 3);
-    // chunks t+2 and t+3 (10 instructions) may stay in flight; near the end of the split fewer were issued
+    // chunks t+2 and t+3 (2 x 5 instructions, 2 x 4 for the waves without a second dy instruction) may stay in flight;
+    // near the end of the split fewer were issued
     auto retire = [&]() {
-      if (t + 3 < nchunks) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (t + 3 >= nchunks) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (d_count == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     };
     if (grp == 1) retire();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1299,7 +1324,8 @@ int vkas_gemm_tn_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* d
   const long dy_bytes = ((M - 1) * lddy + Np) * 2;
   if (!no_slab && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1 && g->Hout == g->Hin && g->Wout == g->Win &&
       g->Win % 64 == 0 && M >= 65536 && Np >= 112 && g->Cp >= 128 && x_bytes < 0xFFFFFFF0L && dy_bytes < 0xFFFFFFF0L) {
-    const long tiles = vkas_cdiv(Np, 128) * 3 * vkas_cdiv(g->Cp, 128);
+    const bool n112 = vkas_cdiv(Np, 112) * 112 < vkas_cdiv(Np, 128) * 128;  // 112-channel tiles when they pad less
+    const long tiles = vkas_cdiv(Np, n112 ? 112 : 128) * 3 * vkas_cdiv(g->Cp, 128);
     const long chunks = M / 64;
     // Pixel splits: whole splits per XCD (multiple of 8).  The tiles of one split walk the same dy / x chunks at the same
     // time and share them through that XCD's L2 (every operand byte is used by 9 tiles): keeping a split's tiles
@@ -1310,9 +1336,14 @@ int vkas_gemm_tn_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* d
     if (splits > chunks / 16) splits = chunks / 16 > 0 ? chunks / 16 : 1;
     const long cps = vkas_cdiv(chunks, splits);
     splits = vkas_cdiv(chunks, cps);
-    conv3x3_wgrad_slab_kernel<<<(unsigned)(tiles * splits), 512, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy, Np, M, K,
-                                                                          (int)cps, gw, gb, (unsigned)x_bytes,
-                                                                          (unsigned)dy_bytes);
+    if (n112)
+      conv3x3_wgrad_slab_kernel<7><<<(unsigned)(tiles * splits), 512, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy, Np, M,
+                                                                               K, (int)cps, gw, gb, (unsigned)x_bytes,
+                                                                               (unsigned)dy_bytes);
+    else
+      conv3x3_wgrad_slab_kernel<8><<<(unsigned)(tiles * splits), 512, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy, Np, M,
+                                                                               K, (int)cps, gw, gb, (unsigned)x_bytes,
+                                                                               (unsigned)dy_bytes);
     VKAS_LAUNCH_CHECK("conv3x3_wgrad_slab");
     return VKAS_OK;
   }

@@ -8,6 +8,7 @@ needs with the pack kernels.  Every op launches on torch's current HIP stream an
 torch's caching allocator; nothing here falls back to torch math or to the CPU.
 """
 import ctypes
+import weakref
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -88,24 +89,67 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------------------- raw wrappers
-def pack_conv_weight(w: torch.Tensor, Np: int, Cp: int, mode: int, dtype: torch.dtype) -> torch.Tensor:
-    w4 = w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
-    N, C, KH, KW = w4.shape
-    out = torch.empty((Np * KH * KW * Cp,), dtype=dtype, device=w.device)
-    check(lib.vkas_pack_conv_weight(_p(w4.contiguous()), _p(out), N, C, KH, KW, Np, Cp, mode,
-                                    _lib.BF16 if dtype == torch.bfloat16 else _lib.F32, _stream()), 'pack_conv_weight')
+# Packed operands derived from parameters (GEMM weight layouts, padded vectors) are cached between the uses of one
+# parameter value: a weight is used by the forward and the backward of both passes of a step, i.e. packed once per
+# layout instead of four times.  An entry is valid while the source storage, its autograd version counter and the
+# epoch below are unchanged; the fused optimizer writes parameters through the C ABI (no version bump) and bumps the
+# epoch instead (training/optimizer.py).
+_PACK_CACHE = {}
+_PACK_EPOCH = [0]
+
+
+def invalidate_packed_params():
+    _PACK_EPOCH[0] += 1
+    _PACK_CACHE.clear()
+
+
+def _cached_pack(src: torch.Tensor, key, build):
+    # only leaf parameters have a stable identity; anything else (temporaries, concatenated head weights) is rebuilt
+    if not (src.is_leaf and src.requires_grad):
+        return build()
+    k = (id(src), key)
+    ent = _PACK_CACHE.get(k)
+    stamp = (src._version, _PACK_EPOCH[0], src.data_ptr())
+    if ent is not None and ent[0] == stamp and ent[1]() is src:  # the weak reference guards against a recycled id()
+        return ent[2]
+    out = build()
+    _PACK_CACHE[k] = (stamp, weakref.ref(src), out)
     return out
+
+
+def pack_conv_weight(w: torch.Tensor, Np: int, Cp: int, mode: int, dtype: torch.dtype) -> torch.Tensor:
+    def build():
+        w4 = w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
+        N, C, KH, KW = w4.shape
+        out = torch.empty((Np * KH * KW * Cp,), dtype=dtype, device=w.device)
+        check(lib.vkas_pack_conv_weight(_p(w4.contiguous()), _p(out), N, C, KH, KW, Np, Cp, mode,
+                                        _lib.BF16 if dtype == torch.bfloat16 else _lib.F32, _stream()), 'pack_conv_weight')
+        return out
+    return _cached_pack(w, ('conv', Np, Cp, mode, dtype), build)
+
+
+def pack_dw_weight(w: torch.Tensor, C: int, Cp: int, flip: int) -> torch.Tensor:
+    def build():
+        out = torch.empty((49 * Cp,), dtype=_FLOAT, device=w.device)
+        check(lib.vkas_pack_dw_weight(_p(w.contiguous()), _p(out), C, Cp, flip, _stream()), 'pack_dw_weight')
+        return out
+    return _cached_pack(w, ('dw', C, Cp, flip), build)
 
 
 def pad_vector(v: Optional[torch.Tensor], npad: int) -> Optional[torch.Tensor]:
     if v is None:
         return None
-    v = v.reshape(-1)
-    if v.numel() == npad and v.is_contiguous():
+    if v.dim() == 1 and v.numel() == npad and v.is_contiguous():
         return v
-    out = torch.empty((npad,), dtype=_FLOAT, device=v.device)
-    check(lib.vkas_pad_vector(_p(v.contiguous()), _p(out), v.numel(), npad, _stream()), 'pad_vector')
-    return out
+
+    def build():
+        flat = v.reshape(-1)
+        if flat.numel() == npad and flat.is_contiguous():
+            return flat
+        out = torch.empty((npad,), dtype=_FLOAT, device=v.device)
+        check(lib.vkas_pad_vector(_p(flat.contiguous()), _p(out), flat.numel(), npad, _stream()), 'pad_vector')
+        return out
+    return _cached_pack(v, ('pad', npad), build)
 
 
 def _geom(B, Hin, Win, Hout, Wout, Cp, ldx, KH, KW, stride, pad) -> ConvGeom:
@@ -556,8 +600,7 @@ class ConvNextLayer(Function):
         M = B * H * W
         dt, st = _dt(x), _stream()
         # depthwise 7x7
-        wdw = torch.empty((49 * Cp,), dtype=_FLOAT, device=x.device)
-        check(lib.vkas_pack_dw_weight(_p(dw_w.contiguous()), _p(wdw), C, Cp, 0, st), 'pack_dw_weight')
+        wdw = pack_dw_weight(dw_w, C, Cp, 0)
         y = new_act(B, H, W, Cp, x)
         check(lib.vkas_dwconv7x7_fwd(_p(x), act_ld(x), _p(wdw), _p(pad_vector(dw_b, Cp)), None, 0, _p(y), Cp, B, H, W,
                                      Cp, dt, st), 'dwconv7x7_fwd')
@@ -630,8 +673,7 @@ class ConvNextLayer(Function):
         check(lib.vkas_unpack_dw_wgrad(_p(gdw), _p(gdw_ref), C, Cp, 0, st), 'unpack_dw_wgrad')
         dx = None
         if ctx.needs_input_grad[0]:
-            wflip = torch.empty((49 * Cp,), dtype=_FLOAT, device=dev)
-            check(lib.vkas_pack_dw_weight(_p(dw_w.contiguous()), _p(wflip), C, Cp, 1, st), 'pack_dw_weight')
+            wflip = pack_dw_weight(dw_w, C, Cp, 1)
             dx = new_act(B, H, W, Cp, x)
             check(lib.vkas_dwconv7x7_fwd(_p(dy), Cp, _p(wflip), None, _p(dout), act_ld(dout), _p(dx), Cp, B, H, W, Cp,
                                          dt, st), 'dwconv7x7_dgrad')

@@ -8,6 +8,7 @@ import torch
 from torch import nn
 
 from .flat import FlatBuffers
+from .. import ops
 from .._lib import lib, check
 
 
@@ -64,6 +65,7 @@ class FlatAdamW:
                                   sumsq, float(self.max_grad_norm or 0.0), float(grad_scale),
                                   float(self.lr if lr is None else lr), self.betas[0], self.betas[1], self.eps,
                                   self.weight_decay, self.step_count, st), 'adamw_step')
+        ops.invalidate_packed_params()  # parameters changed behind autograd's version counters
 
     def grad_norm(self) -> float:
         """Host-visible total norm of the last step (forces a sync; for logging only)."""
