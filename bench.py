@@ -23,6 +23,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBS = 8000.0                  # same guide: HBM3E peak (about 6.3 TB/s achievable)
 
 
 def synthetic_batches(batch, hw, device, seed):
@@ -194,36 +195,48 @@ def main():
                       f'{nb_ / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0:6.2f} {roof_ / args.steps:8.3f}', file=sys.stderr)
             print(f'[bench] all GEMMs: {tot_ms / args.steps:.2f} ms/step, roofline {tot_roof / args.steps:.2f} ms/step',
                   file=sys.stderr)
-        # dominant kernel = the instantiation with the largest share of the timed region
+        # dominant kernel = the instantiation with the largest share of the timed region.  Its roof is whichever of the
+        # two bounds is tighter for the launches it ran: algorithmic flops / dense bf16 MFMA peak or algorithmic bytes /
+        # HBM peak (the short-K layer GEMMs are HBM-bound, the 3x3 head convolutions MFMA-bound).
         dom = max(summ, key=lambda k: summ[k]['ms']) if summ else 'none'
-        d = summ.get(dom, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
-        achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
-        names = {'gemm_nt_mfma<256x192>': 'gemm_nt_mfma_kernel<4,2,4,6>', 'gemm_nt_mfma<256x224>': 'gemm_nt_mfma_kernel<4,2,4,7>',
-                 'gemm_nt_mfma<256x128>': 'gemm_nt_mfma_kernel<4,2,4,4>', 'gemm_nt_mfma<128x128>': 'gemm_nt_mfma_kernel<2,2,4,4>',
-                 'gemm_tn_mfma<224x256>': 'gemm_tn_mfma_kernel<2,4,7,4>', 'gemm_tn_mfma<192x256>': 'gemm_tn_mfma_kernel<2,4,6,4>',
-                 'gemm_tn_mfma<128x128>': 'gemm_tn_mfma_kernel<2,2,4,4>'}
+
+        def stats(k):
+            fl = sum(r[3] for r in timer.records if r[0] == k)
+            nb = sum(r[7] for r in timer.records if r[0] == k)
+            ms_ = summ[k]['ms']
+            t_mfma, t_hbm = fl / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12), nb / (HBM_PEAK_GBS * 1e9)
+            bound = 'mfma' if t_mfma >= t_hbm else 'hbm'
+            ach = fl / (ms_ * 1e-3) / 1e12 if bound == 'mfma' else nb / (ms_ * 1e-3) / 1e9
+            peak = MFMA_BF16_DENSE_PEAK_TFLOPS if bound == 'mfma' else HBM_PEAK_GBS
+            return {'bound': bound, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
+                    'frac': round(ach / peak, 4), 'launches_per_step': summ[k]['launches'] / max(args.steps, 1),
+                    'avg_launch_ms': round(ms_ / max(summ[k]['launches'], 1), 4),
+                    'algorithmic_flops_per_launch': fl / max(summ[k]['launches'], 1),
+                    'algorithmic_bytes_per_launch': nb / max(summ[k]['launches'], 1),
+                    'share_of_step_time': round(ms_ / (1000.0 * elapsed), 3)}
+
         traffic = None
         pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         default_cfg = (args.size == 1024 and args.batch == 8 and args.dtype == 'bf16')
         if default_cfg and os.path.exists(pmc_path):  # per-launch HBM bytes from the rocprofv3 --pmc passes of this command
-            pmc = json.load(open(pmc_path)).get(names.get(dom, dom))
+            pmc = json.load(open(pmc_path)).get(dom)
             if pmc:
                 traffic = pmc['bytes_per_launch']
         all_gemm_flops = sum(v['flops'] for v in summ.values())
         all_gemm_ms = sum(v['ms'] for v in summ.values())
-        roof = {'bound': 'mfma', 'kernel': f'{names.get(dom, dom)} (implicit-GEMM conv, bf16 v_mfma_f32_16x16x32_bf16)',
-                'achieved': round(achieved, 2), 'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), 'traffic': traffic,
-                'launches_per_step': d['launches'] / max(args.steps, 1),
-                'avg_launch_ms': round(d['ms'] / max(d['launches'], 1), 4),
-                'flops_per_launch': d['flops'] / max(d['launches'], 1),
-                'share_of_step_time': round(d['ms'] / (1000.0 * elapsed), 3),
-                'all_mfma_kernels': {'tflops': round(all_gemm_flops / (all_gemm_ms * 1e-3) / 1e12, 2) if all_gemm_ms > 0 else 0.0,
-                                     'share_of_step_time': round(all_gemm_ms / (1000.0 * elapsed), 3)},
-                'other_kernels': {names.get(k, k): {'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else 0.0,
-                                                    'avg_launch_ms': round(v['ms'] / max(v['launches'], 1), 4),
-                                                    'share_of_step_time': round(v['ms'] / (1000.0 * elapsed), 3)}
-                                  for k, v in summ.items() if k != dom}}
+        if summ:
+            roof = stats(dom)
+            roof = {'bound': roof['bound'], 'kernel': dom, 'achieved': roof['achieved'], 'peak': roof['peak'],
+                    'unit': roof['unit'], 'frac': roof['frac'], 'traffic': traffic,
+                    **{k: v for k, v in roof.items() if k not in ('bound', 'achieved', 'peak', 'unit', 'frac')},
+                    'all_gemm_kernels': {'tflops': round(all_gemm_flops / (all_gemm_ms * 1e-3) / 1e12, 2) if all_gemm_ms > 0 else 0.0,
+                                         'share_of_step_time': round(all_gemm_ms / (1000.0 * elapsed), 3)},
+                    'other_kernels': {k: {kk: vv for kk, vv in stats(k).items()
+                                          if kk in ('bound', 'achieved', 'unit', 'frac', 'avg_launch_ms', 'share_of_step_time')}
+                                      for k in summ if k != dom}}
+        else:
+            roof = {'bound': 'mfma', 'kernel': 'none', 'achieved': 0.0, 'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': 0.0, 'traffic': None}
         out = {'metric': 'images/sec fwd+bwd @1024x1024 bf16 (train step: rough+precise passes, losses, backward, '
                          'clip, AdamW)', 'value': round(images / (elapsed / args.steps), 3), 'unit': 'images/s',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),

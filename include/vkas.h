@@ -124,6 +124,10 @@ int vkas_conv_gemm_wgrad(const void* x, const vkas_conv_geom* g, const void* dy,
  * N extent 128 / 192 / 224 of the 256-row 8-wave tile; wgrad: N extent 128 (4 waves) or 192 / 224 (8 waves); 0 when the
  * plain fp32-FMA kernels are forced (VKAS_GEMM=simple). */
 int vkas_conv_gemm_tile(int wgrad, long M, int Np, int K);
+/* profiling aid: the kernel a bf16 call with this geometry runs.  0 = plain fp32-FMA kernels forced.  fwd: 1 / 128 / 192 /
+ * 224 as above, 1000 + TN = the 3x3 row-slab kernel conv3x3_slab_mfma_kernel<TN, .> (TN = 4, 6, 7); wgrad: 128 / 192 /
+ * 224, 2000 + TNn = conv3x3_wgrad_slab_kernel<TNn> (7, 8).  head_width > 0 for a fused-head launch (widest head). */
+int vkas_conv_gemm_kernel_id(int wgrad, const vkas_conv_geom* g, int Np, long lddy, int head_width);
 /* column sums: out[n] (+)= sum_m y[m][n]   (bias gradients) */
 int vkas_colsum(const void* y, long ld, long M, int Np, float* out, int accumulate, float* ws, size_t ws_bytes,
                 int dtype, void* stream);

@@ -19,6 +19,12 @@ def short(name):
     m = re.search(r'(gemm_nt_mfma_kernel|gemm_tn_mfma_kernel)ILi(\d)ELi(\d)ELi(\d)ELi(\d)E', name)
     if m:
         return f'{m.group(1)}<{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)}>'
+    m = re.search(r'(conv3x3_slab_mfma_kernel)ILi(\d)ELb(\d)E', name)
+    if m:
+        return f'{m.group(1)}<{m.group(2)},{m.group(3)}>'
+    m = re.search(r'(conv3x3_wgrad_slab_kernel)ILi(\d)E', name)
+    if m:
+        return f'{m.group(1)}<{m.group(2)}>'
     m = re.search(r'N_1\d+([a-z0-9_]+_kernel)', name)
     if m:
         return m.group(1)

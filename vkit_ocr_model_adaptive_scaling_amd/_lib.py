@@ -69,6 +69,7 @@ _SIGS = {
     'vkas_conv_gemm_fwd': (c_int, [_P, POINTER(ConvGeom), _P, c_int, POINTER(Epilogue), c_int, _P]),
     'vkas_conv_gemm_wgrad': (c_int, [_P, POINTER(ConvGeom), _P, c_long, c_int, _P, _P, c_int, _P]),
     'vkas_conv_gemm_tile': (c_int, [c_int, c_long, c_int, c_int]),
+    'vkas_conv_gemm_kernel_id': (c_int, [c_int, POINTER(ConvGeom), c_int, c_long, c_int]),
     'vkas_colsum': (c_int, [_P, c_long, c_long, c_int, _P, c_int, _P, c_size_t, c_int, _P]),
     'vkas_colsum_ws_bytes': (c_size_t, [c_long, c_int]),
     'vkas_dwconv7x7_fwd': (c_int, [_P, c_long, _P, _P, _P, c_long, _P, c_long, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -11,6 +11,9 @@ int vkas_gemm_tn_mfma_bf16(const void*, const vkas_conv_geom*, const void*, long
 
 int vkas_gemm_nt_tile_choice(long M, int Np);
 int vkas_gemm_tn_tile_choice(long M, int Np, int K);
+bool vkas_nt_slab_eligible(const vkas_conv_geom* g, int Np);
+bool vkas_tn_slab_eligible(const vkas_conv_geom* g, int Np, long lddy);
+bool vkas_tn_slab_n112(int Np);
 
 static thread_local char g_err[512] = "";
 
@@ -102,6 +105,24 @@ extern "C" int vkas_conv_gemm_fwd(const void* x, const vkas_conv_geom* g, const 
 extern "C" int vkas_conv_gemm_tile(int wgrad, long M, int Np, int K) {
   if (force_simple()) return 0;
   return wgrad ? vkas_gemm_tn_tile_choice(M, Np, K) : vkas_gemm_nt_tile_choice(M, Np);
+}
+
+// Which kernel a bf16 call with this geometry runs: 0 plain fp32-FMA kernels forced; fwd: 1 = 128x128, 128 / 192 / 224 =
+// N extent of the generic 256-row tile, 1000 + TN = conv3x3_slab_mfma_kernel<TN, .> (TN = 4, 6, 7); wgrad: 128 / 192 /
+// 224 generic, 2000 + TNn = conv3x3_wgrad_slab_kernel<TNn>.  head_width > 0: a fused-head launch whose widest head has
+// that many columns.
+extern "C" int vkas_conv_gemm_kernel_id(int wgrad, const vkas_conv_geom* g, int Np, long lddy, int head_width) {
+  if (force_simple() || !g) return 0;
+  const long M = (long)g->B * g->Hout * g->Wout;
+  const int K = g->KH * g->KW * g->Cp;
+  if (wgrad) {
+    if (vkas_tn_slab_eligible(g, Np, lddy)) return 2000 + (vkas_tn_slab_n112(Np) ? 7 : 8);
+    return vkas_gemm_tn_tile_choice(M, Np, K);
+  }
+  int choice = vkas_gemm_nt_tile_choice(M, Np);
+  if (head_width > 0) choice = head_width <= 128 ? 128 : (head_width <= 192 ? 192 : 224);
+  if (choice != 1 && vkas_nt_slab_eligible(g, Np)) return 1000 + choice / 32;
+  return choice;
 }
 
 extern "C" int vkas_conv_gemm_wgrad(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np,

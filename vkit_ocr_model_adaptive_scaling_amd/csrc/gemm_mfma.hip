@@ -1206,6 +1206,30 @@ int vkas_gemm_nt_tile_choice(long M, int Np) {
   return bn;
 }
 
+static bool row_aligned_3x3(const vkas_conv_geom* g, int wmod) {
+  return g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1 && g->Hout == g->Hin && g->Wout == g->Win &&
+         g->Win % wmod == 0;
+}
+
+// conv3x3_slab_mfma_kernel: rows of whole 256-pixel tiles, operands addressable with 32-bit buffer offsets
+bool vkas_nt_slab_eligible(const vkas_conv_geom* g, int Np) {
+  static const bool no_slab = getenv("VKAS_NT_NOSLAB") != nullptr;
+  const long K = (long)g->KH * g->KW * g->Cp;
+  const long a_bytes = (((long)g->B * g->Hin * g->Win - 1) * g->ldx + g->Cp) * 2;
+  return !no_slab && row_aligned_3x3(g, 256) && a_bytes < 0xFFFFFFF0L && (long)Np * K * 2 < 0xFFFFFFF0L;
+}
+
+// conv3x3_wgrad_slab_kernel: rows of whole 64-pixel chunks, at least one full n tile and channel block
+bool vkas_tn_slab_eligible(const vkas_conv_geom* g, int Np, long lddy) {
+  static const bool no_slab = getenv("VKAS_TN_NOSLAB") != nullptr;
+  const long M = (long)g->B * g->Hout * g->Wout;
+  const long x_bytes = (((long)g->B * g->Hin * g->Win - 1) * g->ldx + g->Cp) * 2;
+  const long dy_bytes = ((M - 1) * lddy + Np) * 2;
+  return !no_slab && row_aligned_3x3(g, 64) && M >= 65536 && Np >= 112 && g->Cp >= 128 && x_bytes < 0xFFFFFFF0L &&
+         dy_bytes < 0xFFFFFFF0L;
+}
+bool vkas_tn_slab_n112(int Np) { return vkas_cdiv(Np, 112) * 112 < vkas_cdiv(Np, 128) * 128; }  // 112-wide tiles pad less
+
 int vkas_gemm_nt_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* Bw, int Np, const vkas_epilogue* e,
                            hipStream_t st) {
   const long M = (long)g->B * g->Hout * g->Wout;
@@ -1220,11 +1244,9 @@ int vkas_gemm_nt_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* B
   const bool big = choice != 1;
   const int bn = big ? choice : 128;
   // 3x3 / stride 1 / pad 1 with rows of whole 256-pixel tiles: the row-slab kernel
-  static const bool no_slab = getenv("VKAS_NT_NOSLAB") != nullptr;
   const long a_bytes = (((long)g->B * g->Hin * g->Win - 1) * g->ldx + g->Cp) * 2;
   const long b_bytes = (long)Np * K * 2;
-  if (big && !no_slab && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1 && g->Hout == g->Hin &&
-      g->Wout == g->Win && g->Win % 256 == 0 && a_bytes < 0xFFFFFFF0L && b_bytes < 0xFFFFFFF0L) {
+  if (big && vkas_nt_slab_eligible(g, Np)) {
     const bool head = e->mode == VKAS_EPI_HEAD;
     const long ntn = head ? e->head.n_heads : vkas_cdiv(Np, bn);
     dim3 grid((unsigned)((M / 256) * ntn));
@@ -1319,12 +1341,10 @@ int vkas_gemm_tn_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* d
   const int K = g->KH * g->KW * g->Cp;
   if (M == 0) return VKAS_OK;
   // row-aligned 3x3 / stride 1 / pad 1 with wide operands: the slab kernel
-  static const bool no_slab = getenv("VKAS_TN_NOSLAB") != nullptr;
   const long x_bytes = (((long)g->B * g->Hin * g->Win - 1) * g->ldx + g->Cp) * 2;
   const long dy_bytes = ((M - 1) * lddy + Np) * 2;
-  if (!no_slab && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1 && g->Hout == g->Hin && g->Wout == g->Win &&
-      g->Win % 64 == 0 && M >= 65536 && Np >= 112 && g->Cp >= 128 && x_bytes < 0xFFFFFFF0L && dy_bytes < 0xFFFFFFF0L) {
-    const bool n112 = vkas_cdiv(Np, 112) * 112 < vkas_cdiv(Np, 128) * 128;  // 112-channel tiles when they pad less
+  if (vkas_tn_slab_eligible(g, Np, lddy)) {
+    const bool n112 = vkas_tn_slab_n112(Np);
     const long tiles = vkas_cdiv(Np, n112 ? 112 : 128) * 3 * vkas_cdiv(g->Cp, 128);
     const long chunks = M / 64;
     // Pixel splits: whole splits per XCD (multiple of 8).  The tiles of one split walk the same dy / x chunks at the same

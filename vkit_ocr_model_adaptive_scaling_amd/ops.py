@@ -176,6 +176,19 @@ class LaunchTimer:
 TIMER: Optional[LaunchTimer] = None
 
 
+def nt_kernel_name(kid: int, head: bool) -> str:
+    """rocprofv3-style short name (profiles/parse_pmc.py) of the kernel behind a vkas_conv_gemm_kernel_id() code."""
+    if kid >= 1000:
+        return 'conv3x3_slab_mfma_kernel<%d,%d>' % (kid - 1000, int(head))
+    return 'gemm_nt_mfma_kernel<%s>' % {1: '2,2,4,4', 128: '4,2,4,4', 192: '4,2,4,6', 224: '4,2,4,7'}[kid]
+
+
+def tn_kernel_name(kid: int) -> str:
+    if kid >= 2000:
+        return 'conv3x3_wgrad_slab_kernel<%d>' % (kid - 2000)
+    return 'gemm_tn_mfma_kernel<%s>' % {128: '2,2,4,4', 192: '2,4,6,4', 224: '2,4,7,4'}[kid]
+
+
 def _timed(kind, x, flops, M, N, K, fn, nbytes=0.0):
     if TIMER is None:
         return fn()
@@ -197,11 +210,8 @@ def conv_gemm(x: torch.Tensor, geom: ConvGeom, Bw: torch.Tensor, Np: int, out: t
         M = geom.B * geom.Hout * geom.Wout
         N, K = nk if nk is not None else (Np, geom.KH * geom.KW * geom.Cp)
         if x.dtype == torch.bfloat16:
-            t = lib.vkas_conv_gemm_tile(0, M, Np, geom.KH * geom.KW * geom.Cp)
-            if head is not None:
-                wmax = max(head.np[i] for i in range(head.n_heads))
-                t = 128 if wmax <= 128 else (192 if wmax <= 192 else 224)
-            kind = 'gemm_nt_mfma<%s>' % ('128x128' if t == 1 else '256x%d' % t)
+            wmax = max(head.np[i] for i in range(head.n_heads)) if head is not None else 0
+            kind = nt_kernel_name(lib.vkas_conv_gemm_kernel_id(0, ctypes.byref(geom), Np, 0, wmax), head is not None)
         else:
             kind = 'gemm_nt_simple'
         es = x.element_size()
@@ -242,8 +252,7 @@ def conv_wgrad(x: torch.Tensor, geom: ConvGeom, dy: torch.Tensor, Np: int, nk=No
                                        _stream()), 'conv_gemm_wgrad')
         return (gw, gb) if with_bias else gw
     if x.dtype == torch.bfloat16:
-        t = lib.vkas_conv_gemm_tile(1, M, Np, K)
-        kind = 'gemm_tn_mfma<%s>' % ('128x128' if t == 128 else '%dx256' % t)
+        kind = tn_kernel_name(lib.vkas_conv_gemm_kernel_id(1, ctypes.byref(geom), Np, act_ld(dy), 0))
     else:
         kind = 'gemm_tn_simple'
     N, Kl = nk if nk is not None else (Np, K)
