@@ -105,17 +105,25 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return cdf + x * pdf;
 }
 
-// bf16-storage variants: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below bf16 resolution) sharing one
-// exp between the cdf and the pdf; about a third of the instructions of erff + expf.  fp32 storage keeps the exact forms.
+// bf16-storage variants.  Phi(x) = 0.5 + x * P(x^2) on |x| <= 4.25 (degree-8 near-minimax fit, fp32 Horner; x clamped
+// outside, where Phi is within 1.1e-5 of 0 / 1): |Phi error| <= 1.3e-5, |gelu error| <= 5e-5 - below half a bf16 ulp
+// for every |gelu(x)| > 0.03 - with 12 plain VALU operations and no transcendental (the erf / exp form cost as much as
+// the MFMAs of a short-K layer GEMM in its epilogue).  phi(x) needs one v_exp_f32 and is only computed when the
+// derivative is wanted.  fp32 storage keeps the exact forms.
 __device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& pdf_x) {
-  const float ax = fabsf(x);
-  const float e = __expf(-0.5f * x * x);
-  // 1 / (1 + p*|x|/sqrt2), p = 0.3275911: v_rcp_f32 (1 ulp), not the ~10-instruction IEEE division sequence
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.2316418881f, ax, 1.0f));
-  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-  const float half_erfc = 0.5f * poly * e;                    // 0.5 * erfc(|x|/sqrt2)
-  cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
-  pdf_x = 0.39894228040143268f * e;
+  const float xc = __builtin_amdgcn_fmed3f(x, -4.25f, 4.25f);
+  const float u = xc * xc;
+  float p = 5.5648210864e-11f;
+  p = fmaf(p, u, -5.3277341912e-09f);
+  p = fmaf(p, u, 2.2554223425e-07f);
+  p = fmaf(p, u, -5.6264222408e-06f);
+  p = fmaf(p, u, 9.3418689023e-05f);
+  p = fmaf(p, u, -1.1085611169e-03f);
+  p = fmaf(p, u, 9.8159725707e-03f);
+  p = fmaf(p, u, -6.6344495031e-02f);
+  p = fmaf(p, u, 3.9890234175e-01f);
+  cdf = fmaf(xc, p, 0.5f);
+  pdf_x = 0.39894228040143268f * __expf(-0.5f * x * x);
 }
 template <typename T> __device__ __forceinline__ float gelu_t(float x);
 template <> __device__ __forceinline__ float gelu_t<float>(float x) { return gelu_f(x); }

@@ -178,12 +178,16 @@ TIMER: Optional[LaunchTimer] = None
 
 def nt_kernel_name(kid: int, head: bool) -> str:
     """rocprofv3-style short name (profiles/parse_pmc.py) of the kernel behind a vkas_conv_gemm_kernel_id() code."""
+    if kid == 0:
+        return 'gemm_nt_simple'
     if kid >= 1000:
         return 'conv3x3_slab_mfma_kernel<%d,%d>' % (kid - 1000, int(head))
     return 'gemm_nt_mfma_kernel<%s>' % {1: '2,2,4,4', 128: '4,2,4,4', 192: '4,2,4,6', 224: '4,2,4,7'}[kid]
 
 
 def tn_kernel_name(kid: int) -> str:
+    if kid == 0:
+        return 'gemm_tn_simple'
     if kid >= 2000:
         return 'conv3x3_wgrad_slab_kernel<%d>' % (kid - 2000)
     return 'gemm_tn_mfma_kernel<%s>' % {128: '2,2,4,4', 192: '2,4,6,4', 224: '2,4,7,4'}[kid]
