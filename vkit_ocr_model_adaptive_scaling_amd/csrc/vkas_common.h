@@ -134,10 +134,22 @@ template <> __device__ __forceinline__ float gelu_t<bf16_t>(float x) {
 }
 template <typename T> __device__ __forceinline__ float dgelu_t(float x);
 template <> __device__ __forceinline__ float dgelu_t<float>(float x) { return dgelu_f(x); }
+// gelu'(x) = Phi(x) + x phi(x) = 0.5 + x * Q(x^2) on |x| <= 4.5 (degree 9, |error| <= 1.8e-4 of a value in [−0.13, 1.13];
+// clamped outside): the derivative-only sites (GELU' epilogue of the MLP dgrad) need no exp either.
 template <> __device__ __forceinline__ float dgelu_t<bf16_t>(float x) {
-  float cdf, pdf;
-  gelu_parts_fast(x, cdf, pdf);
-  return fmaf(x, pdf, cdf);
+  const float xc = __builtin_amdgcn_fmed3f(x, -4.5f, 4.5f);
+  const float u = xc * xc;
+  float p = -2.2107989521e-11f;
+  p = fmaf(p, u, 2.5213160948e-09f);
+  p = fmaf(p, u, -1.2680528206e-07f);
+  p = fmaf(p, u, 3.7219336900e-06f);
+  p = fmaf(p, u, -7.1221943086e-05f);
+  p = fmaf(p, u, 9.4054174145e-04f);
+  p = fmaf(p, u, -8.8158577153e-03f);
+  p = fmaf(p, u, 5.8609299903e-02f);
+  p = fmaf(p, u, -2.6492567818e-01f);
+  p = fmaf(p, u, 7.9762614621e-01f);
+  return fmaf(xc, p, 0.5f);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
