@@ -101,6 +101,9 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--detail', action='store_true', help='per-shape GEMM timing table on stderr')
+    ap.add_argument('--schedule', choices=('merged', 'two-pass'), default='merged',
+                    help='merged: one backbone pass over the rough + precise batches and one backward of the summed loss '
+                         '(same gradients); two-pass: the reference order, rough fwd/bwd then precise fwd/bwd')
     args = ap.parse_args()
 
     import torch
@@ -136,7 +139,8 @@ def main():
     opt = FlatAdamW(None, lr=8e-4, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=2.5, flat=flat)
     reducer = BucketedGradReducer(flat, adaptive_scaling_buckets(model)) if world > 1 else None
     step = TwoPassStep(model, AdaptiveScalingRoughLossFunction(AdaptiveScalingRoughLossFunctionConifg()),
-                       AdaptiveScalingPreciseLossFunction(AdaptiveScalingPreciseLossFunctionConifg()), opt, reducer)
+                       AdaptiveScalingPreciseLossFunction(AdaptiveScalingPreciseLossFunctionConifg()), opt, reducer,
+                       merge_backbone=(args.schedule == 'merged'))
     hw = (args.size, args.size)
     rough, precise = synthetic_batches(args.batch, hw, device, 1337 + rank)
     torch.manual_seed(99 + rank)  # stochastic-depth masks differ per rank
@@ -245,7 +249,8 @@ def main():
                                                            f'{args.size}x{args.size}, batch {args.batch} per pass per GPU '
                                                            f'(BASELINE.json configs[2]{"/[3]" if world > 1 else ""})',
                                                'global_batch': args.batch * world, 'images_per_step': images,
-                                               'parallelism': f'dp{world}', 'losses': [round(rl, 5), round(pl, 5)]},
+                                               'parallelism': f'dp{world}', 'pass_schedule': args.schedule,
+                                               'losses': [round(rl, 5), round(pl, 5)]},
                'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(hw, 1337)

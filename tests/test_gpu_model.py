@@ -179,6 +179,44 @@ def test_full_model_tiny_256(kind, dtype):
     assert n2 > n1 > 100
 
 
+@pytest.mark.parametrize('dtype', DTYPES, ids=IDS)
+def test_merged_schedule_matches_two_pass(dtype):
+    """model.forward_both (one backbone pass over rough + precise batch, one backward of the summed loss) gives the outputs
+    and the accumulated gradients of the reference's two-pass order, and hence matches the reference fixture too."""
+    from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
+                                                           AdaptiveScalingNeckHeadType)
+    from vkit_ocr_model_adaptive_scaling_amd.loss_function import (
+        Box, AdaptiveScalingRoughLossFunction, AdaptiveScalingRoughLossFunctionConifg,
+        AdaptiveScalingPreciseLossFunction, AdaptiveScalingPreciseLossFunctionConifg)
+    g = golden('full_tiny_upernext_256')
+    two = _full_model_run('upernext', dtype)
+    Fm = recipe.FULL_MODEL
+    model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.TINY, AdaptiveScalingNeckHeadType.UPERNEXT),
+                            compute_dtype=dtype)
+    seed_module(model, Fm['seed'], Fm['std'])
+    model.cuda().eval()
+    t = {k: torch.from_numpy(v).cuda() for k, v in recipe.full_model_inputs(Fm).items()}
+    box = Box(*Fm['core_box'])
+    (mask, height), pouts = model.forward_both(t['image_rough'], t['image_precise'])
+    rl = AdaptiveScalingRoughLossFunction(AdaptiveScalingRoughLossFunctionConifg())(
+        mask, height, t['gt_mask'], t['gt_score_rough'], Fm['down_shape'], box)
+    pl = AdaptiveScalingPreciseLossFunction(AdaptiveScalingPreciseLossFunctionConifg())(
+        None, *pouts, t['gt_score_precise'], t['gt_mask'], Fm['down_shape'], box, t['py'], t['px'], t['gt_offsets'],
+        t['gt_angles'], t['gt_dists'])
+    (rl / 2 + pl / 2).backward()
+    outs = dict(rough_mask=mask, rough_height=height, precise_prob=pouts[0], precise_offset=pouts[1],
+                precise_angle=pouts[2], precise_dist=pouts[3])
+    for n, o in outs.items():
+        assert rel_err(o.detach(), two[n]) < (1e-6 if dtype == torch.float32 else 2e-3), n
+        assert rel_err(o.detach(), g[n]) < FWD_TOL[dtype], n
+    grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert set(grads) == set(two['both_grads'])
+    worst = max(rel_err(grads[n], two['both_grads'][n]) for n in grads)
+    print('merged vs two-pass: worst gradient rel err', dtype, worst)
+    assert worst < (2e-5 if dtype == torch.float32 else 3e-2)
+    check_grad_summary(grads, g, tol=GRAD_TOL[dtype], prefix='both/')
+
+
 def test_full_model_deterministic_forward():
     """Run-to-run bitwise reproducibility of the forward path (no float atomics on it)."""
     a = _full_model_run('upernext', torch.bfloat16)

@@ -1095,7 +1095,9 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const bf16_t* _
     }
     asm volatile("" ::: "memory");
     const bool issued = t + 3 < nchunks;
-    if (issued) issue_chunk((t + 3) & 3);
+    if constexpr ((ABL & 1) == 0) {
+      if (issued) issue_chunk((t + 3) & 3);
+    }
     // chunks t+2 and t+3 (2 x 5 instructions, 2 x 4 for the waves without a second dy instruction) may stay in flight;
     // near the end of the split fewer were issued
     auto retire = [&]() {
@@ -1108,15 +1110,25 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const bf16_t* _
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     // ---- MFMA phase
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr ((ABL & 16) != 0) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h) {
 #pragma unroll
-      for (int i = 0; i < TNn; ++i)
+        for (int i = 0; i < TNn; ++i) asm volatile("" ::"v"(fd[h][i]));
 #pragma unroll
-        for (int j = 0; j < TK; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[h][i], fx[h][j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+        for (int j = 0; j < TK; ++j) asm volatile("" ::"v"(fx[h][j]));
+      }
+    } else {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < TNn; ++i)
+#pragma unroll
+          for (int j = 0; j < TK; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[h][i], fx[h][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
     if (do_bias) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)

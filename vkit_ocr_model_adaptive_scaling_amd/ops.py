@@ -785,6 +785,31 @@ class Cat(Function):
         return tuple(outs)
 
 
+class SplitBatch(Function):
+    """x -> (x[:b0], x[b0:]) as views of one NHWC activation; backward writes the two gradients into the halves of one
+    buffer (no zero-fill + add, which is what slicing through autograd would do).  Used by the merged pass schedule
+    (model.forward_both): the backbone runs once on the rough and the precise batch, each neck reads its half."""
+
+    @staticmethod
+    def forward(ctx, x, b0: int):
+        _require_cuda(x)
+        x = as_act(x)
+        ctx.meta = (tuple(x.shape), b0, x.dtype)
+        return x[:b0], x[b0:]
+
+    @staticmethod
+    def backward(ctx, d0, d1):
+        shape, b0, dtype = ctx.meta
+        ref = d0 if d0 is not None else d1
+        out = torch.empty(shape, dtype=dtype, device=ref.device)
+        for part, d in ((out[:b0], d0), (out[b0:], d1)):
+            if d is None:
+                part.zero_()
+            else:
+                copy_channels(as_act(d), part)
+        return out, None
+
+
 class ToNchw(Function):
     """(B,H,W,Cp) activation -> (B,C,H,W) fp32 NCHW: the permute back of model/upernext.py:223 / fpn.py:183 for the
     1..4-channel head outputs."""

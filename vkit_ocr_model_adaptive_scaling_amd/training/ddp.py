@@ -114,33 +114,48 @@ class TwoPassStep:
     """One training step with the reference's semantics (train.py:397-478): rough forward/loss/backward, precise
     forward/loss/backward (gradients accumulate), gradient all-reduce, global-norm clip, AdamW."""
 
-    def __init__(self, model, rough_loss_fn, precise_loss_fn, optimizer, reducer: Optional[BucketedGradReducer] = None):
+    def __init__(self, model, rough_loss_fn, precise_loss_fn, optimizer, reducer: Optional[BucketedGradReducer] = None,
+                 merge_backbone: bool = False):
+        """merge_backbone: run the backbone once over both batches (model.forward_both) and back-propagate
+        rough_loss + precise_loss in one backward: the same gradients as the two accumulating passes (the sum is taken
+        in a different order), half the backbone launches."""
         self.model, self.rough_loss_fn, self.precise_loss_fn = model, rough_loss_fn, precise_loss_fn
         self.optimizer, self.reducer = optimizer, reducer
         self.world = reducer.world_size if reducer is not None else 1
         self._backbone_buckets = [b for b in (reducer.buckets if reducer else {}) if b.startswith('backbone')]
+        self.merge_backbone = merge_backbone
+
+    def _rough_loss(self, outs, b, scale):
+        mask, height = outs
+        return self.rough_loss_fn(mask, height, b['downsampled_mask'], b['downsampled_score_map'], b['downsampled_shape'],
+                                  b['downsampled_core_box'], scale=scale)
+
+    def _precise_loss(self, outs, b, scale):
+        prob, offset, angle, dist_ = outs
+        return self.precise_loss_fn(None, prob, offset, angle, dist_, b['downsampled_score_map'], b['downsampled_mask'],
+                                    b['downsampled_shape'], b['downsampled_core_box'], b['downsampled_label_point_y'],
+                                    b['downsampled_label_point_x'], b['up_left_offsets'], b['corner_angles'],
+                                    b['corner_distances'], scale=scale)
 
     def __call__(self, rough_batch: dict, precise_batch: dict, lr: Optional[float] = None):
         scale = 0.5 / self.world  # train.py:413,451 (loss / 2), averaged over ranks
         r = self.reducer
-        mask, height = self.model.forward_rough(rough_batch['image'])
-        rough_loss = self.rough_loss_fn(mask, height, rough_batch['downsampled_mask'],
-                                        rough_batch['downsampled_score_map'], rough_batch['downsampled_shape'],
-                                        rough_batch['downsampled_core_box'], scale=scale)
-        if r is not None:
-            r.arm(['rough'])
-        rough_loss.backward()
-        prob, offset, angle, dist_ = self.model.forward_precise(precise_batch['image'])
-        precise_loss = self.precise_loss_fn(None, prob, offset, angle, dist_, precise_batch['downsampled_score_map'],
-                                            precise_batch['downsampled_mask'], precise_batch['downsampled_shape'],
-                                            precise_batch['downsampled_core_box'],
-                                            precise_batch['downsampled_label_point_y'],
-                                            precise_batch['downsampled_label_point_x'],
-                                            precise_batch['up_left_offsets'], precise_batch['corner_angles'],
-                                            precise_batch['corner_distances'], scale=scale)
-        if r is not None:
-            r.arm(['precise'] + self._backbone_buckets)
-        precise_loss.backward()
+        if self.merge_backbone:
+            rough_out, precise_out = self.model.forward_both(rough_batch['image'], precise_batch['image'])
+            rough_loss = self._rough_loss(rough_out, rough_batch, scale)
+            precise_loss = self._precise_loss(precise_out, precise_batch, scale)
+            if r is not None:
+                r.arm(['rough', 'precise'] + self._backbone_buckets)
+            (rough_loss + precise_loss).backward()
+        else:
+            rough_loss = self._rough_loss(self.model.forward_rough(rough_batch['image']), rough_batch, scale)
+            if r is not None:
+                r.arm(['rough'])
+            rough_loss.backward()
+            precise_loss = self._precise_loss(self.model.forward_precise(precise_batch['image']), precise_batch, scale)
+            if r is not None:
+                r.arm(['precise'] + self._backbone_buckets)
+            precise_loss.backward()
         if r is not None:
             r.flush()
         self.optimizer.step(lr=lr)
