@@ -37,6 +37,9 @@ def timed(fn, iters=5, rounds=5):
 
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'both'
+if len(sys.argv) > 2 and sys.argv[2] == 'merged':  # backbone batch 16 (merged pass schedule)
+    NT = [(2 * m, n, k, mode) for m, n, k, mode in NT]
+    TN = [(2 * m, n, k) for m, n, k in TN]
 tag = f"NT_TILE={os.environ.get('VKAS_NT_TILE', 'auto')} TN_TILE={os.environ.get('VKAS_TN_TILE', 'auto')}"
 if which in ('nt', 'both'):
     for M, N, K, mode in NT:

@@ -1333,7 +1333,7 @@ int vkas_gemm_tn_tile_choice(long M, int Np, int K) {
   static const int force = getenv("VKAS_TN_TILE") ? atoi(getenv("VKAS_TN_TILE")) : 0;
   if (force) return force;
   int bn = 128;
-  if (M >= 16384 && K >= 256) {
+  if (M >= 16384 && K >= 192) {
     long best = vkas_cdiv(Np, 128) * 128;
     const int cand[2] = {192, 224};
     for (int c = 0; c < 2; ++c) {
