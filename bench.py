@@ -173,6 +173,24 @@ def main():
     if not (rl == rl and pl == pl):
         raise SystemExit('non-finite loss in the timed region')
 
+    # also the single-pass rates (forward + loss + backward of one batch of `batch` images, no optimizer),
+    # so that either reading of "batch 8" is covered.  Outside the timed region; one rank only.
+    per_pass = None
+    if world == 1:
+        def pass_ms(run, n=3):
+            run()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                run()
+            torch.cuda.synchronize()
+            return 1000.0 * (time.perf_counter() - t1) / n
+        r_ms = pass_ms(lambda: step._rough_loss(model.forward_rough(rough['image']), rough, 0.5).backward())
+        p_ms = pass_ms(lambda: step._precise_loss(model.forward_precise(precise['image']), precise, 0.5).backward())
+        opt.zero_grad()
+        per_pass = {'rough_only_images_per_s': round(args.batch / (r_ms * 1e-3), 2), 'rough_only_ms': round(r_ms, 2),
+                    'precise_only_images_per_s': round(args.batch / (p_ms * 1e-3), 2), 'precise_only_ms': round(p_ms, 2)}
+
     if rank == 0:
         print(f'[bench] {args.steps} steps in {elapsed:.3f} s on {world} GPU(s); host enqueue {enqueue:.3f} s; '
               f'losses {rl:.4f} {pl:.4f}', file=sys.stderr, flush=True)
@@ -249,7 +267,7 @@ def main():
                                                            f'{args.size}x{args.size}, batch {args.batch} per pass per GPU '
                                                            f'(BASELINE.json configs[2]{"/[3]" if world > 1 else ""})',
                                                'global_batch': args.batch * world, 'images_per_step': images,
-                                               'parallelism': f'dp{world}', 'pass_schedule': args.schedule,
+                                               'parallelism': f'dp{world}', 'pass_schedule': args.schedule, 'per_pass': per_pass,
                                                'losses': [round(rl, 5), round(pl, 5)]},
                'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:
