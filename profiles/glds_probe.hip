@@ -1,4 +1,4 @@
-// Hardware probe: does `buffer_load_dwordx4 ... lds` write zeros for out-of-range lanes, and how do EXEC-masked lanes behave?
+// Hardware probe (hipcc --offload-arch=gfx950 -O3 glds_probe.hip; result recorded in DESIGN.md, section 4): does `buffer_load_dwordx4 ... lds` write zeros for out-of-range lanes, and how do EXEC-masked lanes behave?
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 __global__ void k(const float* p, float* o, unsigned nbytes) {
