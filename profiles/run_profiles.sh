@@ -1,6 +1,6 @@
 set -x
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01v6; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01v7; mkdir -p $O
 timeout -k 10 500 python3 $R/bench.py > $O/bench.log 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/stats.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/fetch.log 2>&1
