@@ -123,6 +123,30 @@ def test_conv(case, dtype):
         close(from_act(xa.grad, Cin), xr.grad, dtype, 'conv dgrad')
 
 
+def test_rowslab_kernels_repeatable():
+    """Race screen for the LDS-DMA row-slab kernels (counted vmcnt + raw barriers): the forward / dgrad kernel has no
+    atomics, so 12 launches on the same operands must agree bit for bit; the weight-gradient kernel (fp32 atomics over the
+    pixel splits) must agree to accumulation order."""
+    ops = ops_mod()
+    torch.manual_seed(3)
+    x = torch.randn((2, 130, 512, 136), device='cuda').bfloat16().requires_grad_(True)   # M = 133120, Cp = 136
+    w = (torch.randn((200, 136, 3, 3), device='cuda') * 0.03).requires_grad_(True)
+    b = torch.randn((200,), device='cuda').requires_grad_(True)
+    cot = torch.randn((2, 130, 512, 200), device='cuda').bfloat16()
+    ys, gxs, gws = [], [], []
+    for _ in range(12):
+        x.grad = w.grad = b.grad = None
+        y = ops.Conv.apply(x, w, b, 1, 1)
+        y.backward(cot)
+        ys.append(y.detach().clone())
+        gxs.append(x.grad.clone())
+        gws.append(w.grad.clone())
+    for y, gx, gw in zip(ys[1:], gxs[1:], gws[1:]):
+        assert torch.equal(y, ys[0])
+        assert torch.equal(gx, gxs[0])
+        assert rel_err(gw, gws[0]) < 1e-5
+
+
 def test_conv_mfma_matches_simple_bitwise_shapes():
     """bf16: the MFMA kernels and the plain fp32-FMA kernels see identical inputs; results agree to accumulation order."""
     import os, subprocess, sys
