@@ -1287,28 +1287,26 @@ static void launch_tn(const void* x, const vkas_conv_geom* g, const void* dy, lo
                       float* gb, hipStream_t st) {
   constexpr int BNn = WN * TNn * 16, BKc = WK * TK * 16;
   const long tiles = vkas_cdiv(Np, BNn) * vkas_cdiv(K, BKc);
-  // Splits over M.  Bounds: (a) about 3 rounds of resident workgroups (256 CUs x 1 block of 8 waves | 2 blocks of 4);
-  // (b) every split adds a full copy of gw with fp32 atomics (~1.3 TB/s chip-wide): at most one split per ~2048
-  // rows keeps that below about half of the MFMA time.  Then prefer a multiple of 8 (whole splits per XCD, see the
-  // kernel's work order) whose per-XCD block count fills whole rounds of that XCD's 32 CUs.
+  // Splits over M: pick the count that minimises a two-term cost model.
+  //   main loop: rounds of resident workgroups (256 CUs x 1 block of 8 waves | 2 blocks of 4) x 64-row iterations of a
+  //     split x time per iteration (measured: ~1.2 us for the 8-wave tiles, ~0.5 us for the 4-wave tile);
+  //   reduction: every split adds a full copy of its tile with fp32 atomics, ~1.3 TB/s chip-wide (MI355X_MICROARCH.md).
+  // On the stage-3/4 weight gradients (M = 16-64 K rows) the atomic tail was half the launch with the old "3 rounds"
+  // rule.  Ties go to multiples of 8 (whole splits per XCD, see the kernel's work order).
   const long resident = 256L * (WN * WK >= 8 ? 1 : 2);
-  long splits = (3 * resident) / tiles;
-  const long max_splits = vkas_cdiv(M, 2048);
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  if (splits >= 8) {
-    const long per_xcd_slots = resident / 8;
-    long best = 8;
-    double best_eff = 0.0;
-    for (long s8 = 8; s8 <= 4 * splits && s8 <= max_splits; s8 += 8) {
-      const long blocks = (s8 / 8) * tiles;
-      const double eff = (double)blocks / (double)(vkas_cdiv(blocks, per_xcd_slots) * per_xcd_slots);
-      if (eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && labs(s8 - splits) < labs(best - splits))) {
-        best_eff = eff;
-        best = s8;
-      }
+  const double t_iter = WN * WK >= 8 ? 1.2e-6 : 0.5e-6;
+  const double tile_bytes = (double)BNn * BKc * 4.0;
+  const long max_splits = vkas_cdiv(M, 4 * TN_ROWS);
+  long splits = 1;
+  double best_t = 1e30;
+  for (long sp = 1; sp <= max_splits && sp * tiles <= 8 * resident; ++sp) {
+    const long blocks = sp * tiles;
+    const double t = (double)vkas_cdiv(blocks, resident) * (double)vkas_cdiv(vkas_cdiv(M, sp), TN_ROWS) * t_iter +
+                     (double)blocks * tile_bytes / 1.3e12;
+    if (t < best_t * (sp % 8 == 0 ? 1.02 : 0.999)) {
+      best_t = t;
+      splits = sp;
     }
-    splits = best;
   }
   if (splits > 65535) splits = 65535;
   long rows = vkas_cdiv(M, splits);
