@@ -191,14 +191,20 @@ __device__ __forceinline__ void pool_bin(int i, int n, int s, int& lo, int& hi) 
   hi = ((i + 1) * n + s - 1) / s;
 }
 
-// one workgroup per (b, bin): the bin's pixels are spread over the threads and reduced through LDS.  nvec <= 256.
+// one workgroup per (b, bin, group of vb channel vectors): the bin's pixels are spread over 256 / vb lanes per vector and
+// reduced through LDS (a 1x1 pooling of a 32x32 map is 1024 pixels per bin: with all 96 vectors in one workgroup only
+// two lanes shared them).  nvec <= 256.
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
-                                                          int B, int H, int W, int s, int nvec) {
+                                                          int B, int H, int W, int s, int nvec_total, int vb) {
   __shared__ float red[256 * 8];
   const int bj = blockIdx.x % s;
   const int bi = (blockIdx.x / s) % s;
   const int b = blockIdx.x / (s * s);
+  const int v_first = blockIdx.y * vb;
+  const int nvec = (nvec_total - v_first < vb) ? nvec_total - v_first : vb;  // vectors of this workgroup
+  x += v_first * 8;
+  y += v_first * 8;
   const int lanes_p = 256 / nvec;
   const int v = threadIdx.x % nvec;
   const int pl = threadIdx.x / nvec;
@@ -333,8 +339,13 @@ extern "C" int vkas_adaptive_avgpool_fwd(const void* x, long ldx, void* y, long 
   if (B == 0) return VKAS_OK;
   VKAS_CHECK(Cp / 8 <= 256, "vkas_adaptive_avgpool_fwd: at most 2048 channels");
   VKAS_DISPATCH_DTYPE(dtype, "vkas_adaptive_avgpool_fwd", {
-    avgpool_fwd_kernel<T><<<(unsigned)((long)B * s * s), 256, 0, vkas_stream(stream)>>>((const T*)x, ldx, (T*)y, ldy, B, H,
-                                                                                       W, s, Cp / 8);
+    // vectors per workgroup: fewer when the bins are large, so that ~64 pixels remain per lane
+    const int nvec = Cp / 8;
+    const long bin_px = (long)vkas_cdiv(H, s) * vkas_cdiv(W, s);
+    int vb = nvec;
+    while (vb > 4 && bin_px * vb > 64L * 256) vb = (vb + 1) / 2;
+    dim3 grid((unsigned)((long)B * s * s), (unsigned)vkas_cdiv(nvec, vb));
+    avgpool_fwd_kernel<T><<<grid, 256, 0, vkas_stream(stream)>>>((const T*)x, ldx, (T*)y, ldy, B, H, W, s, nvec, vb);
   })
   VKAS_LAUNCH_CHECK("adaptive_avgpool_fwd");
   return VKAS_OK;
