@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void dwconv7x7_fwd_kernel(const T* __restrict_
 
 // partial[p][tap][c] = sum over the workgroup's pixels of dy[pix][c] * x[pix + tap][c]; row 49 = sum dy
 template <typename T>
-__global__ __launch_bounds__(256) void dwconv7x7_wgrad_kernel(const T* __restrict__ x, long ldx,
+__global__ __launch_bounds__(256, 2) void dwconv7x7_wgrad_kernel(const T* __restrict__ x, long ldx,
                                                               const T* __restrict__ dy, long lddy,
                                                               float* __restrict__ partial, int H, int W, int Cp,
                                                               int cslices) {
@@ -160,20 +160,36 @@ __global__ __launch_bounds__(256) void dwconv7x7_wgrad_kernel(const T* __restric
       *reinterpret_cast<uint4*>(dtile + p * PIXB + cq * 16) = v;
     }
     __syncthreads();
-    for (int p = pl; p < TY * TX; p += 8) {
-      const int py = p / TX, px = p - py * TX;
-      float d[VEC];
-      load_chunk<T>(dtile + p * PIXB + ch * 16, d);
-      if (ky < 7) {
-        const char* row = tile + ((py + ky) * IX + px) * PIXB + ch * 16;
+    // pixel lane pl walks row pl of the tile left to right with a 7-pixel sliding window of x in registers: one new
+    // x chunk (and one dy chunk) is read and converted per pixel instead of seven (the window slot of x[px + kx] is
+    // (px + kx) % 7, fixed at compile time by unrolling 7 pixels)
+    const char* drow = dtile + (pl * TX) * PIXB + ch * 16;
+    if (ky < 7) {
+      const char* xrow = tile + ((pl + ky) * IX) * PIXB + ch * 16;
+      float win[7][VEC];
 #pragma unroll
-        for (int kx = 0; kx < 7; ++kx) {
-          float xin[VEC];
-          load_chunk<T>(row + kx * PIXB, xin);
+      for (int j = 0; j < 6; ++j) load_chunk<T>(xrow + j * PIXB, win[j]);
+#pragma unroll 1
+      for (int px0 = 0; px0 < TX; px0 += 7) {
 #pragma unroll
-          for (int c = 0; c < VEC; ++c) acc[kx][c] = fmaf(d[c], xin[c], acc[kx][c]);
+        for (int m = 0; m < 7; ++m) {
+          const int px = px0 + m;
+          if (px < TX) {
+            load_chunk<T>(xrow + (px + 6) * PIXB, win[(m + 6) % 7]);
+            float d[VEC];
+            load_chunk<T>(drow + px * PIXB, d);
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+              for (int c = 0; c < VEC; ++c) acc[kx][c] = fmaf(d[c], win[(m + kx) % 7][c], acc[kx][c]);
+            asm volatile("" ::: "memory");  // keep the LDS reads of later pixels here: hoisting all 14 costs 112 VGPRs
+          }
         }
-      } else {
+      }
+    } else {
+      for (int px = 0; px < TX; ++px) {
+        float d[VEC];
+        load_chunk<T>(drow + px * PIXB, d);
 #pragma unroll
         for (int c = 0; c < VEC; ++c) acc[0][c] += d[c];
       }

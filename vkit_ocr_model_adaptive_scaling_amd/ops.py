@@ -312,8 +312,10 @@ def resize_fwd(x, size: Tuple[int, int], mode: int, out=None, accumulate=False):
     B, Hin, Win, Cp = x.shape
     Hout, Wout = size
     y = new_act(B, Hout, Wout, Cp, x) if out is None else out
-    check(lib.vkas_resize_fwd(_p(x), act_ld(x), _p(y), act_ld(y), B, Hin, Win, Hout, Wout, Cp, mode, int(accumulate),
-                              _dt(x), _stream()), 'resize_fwd')
+    nbytes = B * Cp * x.element_size() * (Hin * Win + Hout * Wout * (2 if accumulate else 1))
+    _timed('resize_fwd_kernel', x, 0.0, B * Hout * Wout, Cp, 0,
+           lambda: check(lib.vkas_resize_fwd(_p(x), act_ld(x), _p(y), act_ld(y), B, Hin, Win, Hout, Wout, Cp, mode,
+                                             int(accumulate), _dt(x), _stream()), 'resize_fwd'), nbytes)
     return y
 
 
@@ -321,8 +323,10 @@ def resize_bwd(dy, in_size: Tuple[int, int], mode: int):
     B, Hout, Wout, Cp = dy.shape
     Hin, Win = in_size
     dx = new_act(B, Hin, Win, Cp, dy)
-    check(lib.vkas_resize_bwd(_p(dy), act_ld(dy), _p(dx), act_ld(dx), B, Hin, Win, Hout, Wout, Cp, mode, 0, _dt(dy),
-                              _stream()), 'resize_bwd')
+    nbytes = B * Cp * dy.element_size() * (Hin * Win + Hout * Wout)
+    _timed('resize_bwd_kernel', dy, 0.0, B * Hout * Wout, Cp, 0,
+           lambda: check(lib.vkas_resize_bwd(_p(dy), act_ld(dy), _p(dx), act_ld(dx), B, Hin, Win, Hout, Wout, Cp, mode, 0,
+                                             _dt(dy), _stream()), 'resize_bwd'), nbytes)
     return dx
 
 
@@ -615,8 +619,10 @@ class ConvNextLayer(Function):
         # depthwise 7x7
         wdw = pack_dw_weight(dw_w, C, Cp, 0)
         y = new_act(B, H, W, Cp, x)
-        check(lib.vkas_dwconv7x7_fwd(_p(x), act_ld(x), _p(wdw), _p(pad_vector(dw_b, Cp)), None, 0, _p(y), Cp, B, H, W,
-                                     Cp, dt, st), 'dwconv7x7_fwd')
+        dwb = pad_vector(dw_b, Cp)
+        _timed('dwconv7x7_fwd_kernel', x, 2.0 * 49 * M * C, M, Cp, 49,
+               lambda: check(lib.vkas_dwconv7x7_fwd(_p(x), act_ld(x), _p(wdw), _p(dwb), None, 0, _p(y), Cp, B, H, W, Cp, dt,
+                                                    st), 'dwconv7x7_fwd'), 2.0 * M * Cp * x.element_size())
         # LayerNorm
         yn, stats = layernorm_fwd(y, ln_g.contiguous(), ln_b.contiguous(), C, False)
         # MLP
@@ -680,16 +686,18 @@ class ConvNextLayer(Function):
         gdw, gdb = gdwb[:49 * Cp], gdwb[49 * Cp:]
         nbytes = lib.vkas_dwconv7x7_wgrad_ws_bytes(B, H, W, Cp)
         ws = _ws(nbytes, dev)
-        check(lib.vkas_dwconv7x7_wgrad(_p(x), act_ld(x), _p(dy), Cp, _p(gdw), _p(gdb), _p(ws), nbytes, B, H, W, Cp, dt,
-                                       st), 'dwconv7x7_wgrad')
+        _timed('dwconv7x7_wgrad_kernel', x, 2.0 * 49 * M * C, M, Cp, 49,
+               lambda: check(lib.vkas_dwconv7x7_wgrad(_p(x), act_ld(x), _p(dy), Cp, _p(gdw), _p(gdb), _p(ws), nbytes, B, H, W,
+                                                      Cp, dt, st), 'dwconv7x7_wgrad'), 2.0 * M * Cp * x.element_size())
         gdw_ref = torch.empty((C, 1, 7, 7), dtype=_FLOAT, device=dev)
         check(lib.vkas_unpack_dw_wgrad(_p(gdw), _p(gdw_ref), C, Cp, 0, st), 'unpack_dw_wgrad')
         dx = None
         if ctx.needs_input_grad[0]:
             wflip = pack_dw_weight(dw_w, C, Cp, 1)
             dx = new_act(B, H, W, Cp, x)
-            check(lib.vkas_dwconv7x7_fwd(_p(dy), Cp, _p(wflip), None, _p(dout), act_ld(dout), _p(dx), Cp, B, H, W, Cp,
-                                         dt, st), 'dwconv7x7_dgrad')
+            _timed('dwconv7x7_fwd_kernel', x, 2.0 * 49 * M * C, M, Cp, 49,
+                   lambda: check(lib.vkas_dwconv7x7_fwd(_p(dy), Cp, _p(wflip), None, _p(dout), act_ld(dout), _p(dx), Cp, B, H,
+                                                        W, Cp, dt, st), 'dwconv7x7_dgrad'), 3.0 * M * Cp * x.element_size())
         return (dx, gdw_ref, gdb[:C], dlg, dlb, gw1, db1, gw2, db2[:C], dscale[:C].view(block_scale.shape), None)
 
 
