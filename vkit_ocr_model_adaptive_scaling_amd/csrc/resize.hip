@@ -113,17 +113,41 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ d
   int oy_lo, oy_hi, ox_lo, ox_hi;
   dst_range(iy, Hin, Hout, sy, mode, oy_lo, oy_hi);
   dst_range(ix, Win, Wout, sx, mode, ox_lo, ox_hi);
-  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-    const float wyv = axis_weight(oy, sy, Hin, Hout, iy, mode);
-    if (wyv == 0.f) continue;
-    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-      const float wxv = axis_weight(ox, sx, Win, Wout, ix, mode);
-      if (wxv == 0.f) continue;
-      float t[8];
-      load8(db + ((long)oy * Wout + ox) * lddy, t);
-      const float wgt = wyv * wxv;
+  if (oy_hi - oy_lo < 4 && ox_hi - ox_lo < 4) {
+    // the common x2 case: at most 4 x 4 destinations; the axis weights are evaluated once per axis, not once per pair
+    // (the index arithmetic, not the 16 loads, was the cost of this kernel)
+    float wy4[4], wx4[4];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) acc[k] = fmaf(wgt, t[k], acc[k]);
+    for (int j = 0; j < 4; ++j) {
+      wy4[j] = oy_lo + j <= oy_hi ? axis_weight(oy_lo + j, sy, Hin, Hout, iy, mode) : 0.f;
+      wx4[j] = ox_lo + j <= ox_hi ? axis_weight(ox_lo + j, sx, Win, Wout, ix, mode) : 0.f;
+    }
+#pragma unroll
+    for (int jy = 0; jy < 4; ++jy) {
+      if (wy4[jy] == 0.f) continue;
+#pragma unroll
+      for (int jx = 0; jx < 4; ++jx) {
+        if (wx4[jx] == 0.f) continue;
+        float t[8];
+        load8(db + ((long)(oy_lo + jy) * Wout + ox_lo + jx) * lddy, t);
+        const float wgt = wy4[jy] * wx4[jx];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = fmaf(wgt, t[k], acc[k]);
+      }
+    }
+  } else {
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      const float wyv = axis_weight(oy, sy, Hin, Hout, iy, mode);
+      if (wyv == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const float wxv = axis_weight(ox, sx, Win, Wout, ix, mode);
+        if (wxv == 0.f) continue;
+        float t[8];
+        load8(db + ((long)oy * Wout + ox) * lddy, t);
+        const float wgt = wyv * wxv;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = fmaf(wgt, t[k], acc[k]);
+      }
     }
   }
   T* dst = dx + (((long)b * Hin + iy) * Win + ix) * lddx + v * 8;
