@@ -190,6 +190,12 @@ def main():
         opt.zero_grad()
         per_pass = {'rough_only_images_per_s': round(args.batch / (r_ms * 1e-3), 2), 'rough_only_ms': round(r_ms, 2),
                     'precise_only_images_per_s': round(args.batch / (p_ms * 1e-3), 2), 'precise_only_ms': round(p_ms, 2)}
+        # SURVEY 8(d) pins the unit of work as the reference's order (rough fwd/bwd, then precise fwd/bwd): report that
+        # schedule's step time next to the timed one, whichever of the two was timed
+        other = TwoPassStep(model, step.rough_loss_fn, step.precise_loss_fn, opt, reducer,
+                            merge_backbone=(args.schedule != 'merged'))
+        o_ms = pass_ms(lambda: other(rough, precise, lr=8e-4), n=max(2, min(args.steps, 5)))
+        per_pass['two_pass_ms_per_step' if args.schedule == 'merged' else 'merged_ms_per_step'] = round(o_ms, 2)
 
     if rank == 0:
         print(f'[bench] {args.steps} steps in {elapsed:.3f} s on {world} GPU(s); host enqueue {enqueue:.3f} s; '

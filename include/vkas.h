@@ -228,6 +228,25 @@ int vkas_precise_loss_bwd(const float* prob, const float* offset, const float* a
                           const double* sums, const float* dloss, float* d_prob, float* d_offset, float* d_angle,
                           float* d_dist, void* stream);
 
+/* ---- primitive loss callables: loss_function/__init__.py:12-18 ------------------------------------------- */
+#define VKAS_LOSS_FOCAL 0     /* focal_with_logits.py:18-47: p0 = alpha (< 0: no alpha weighting), p1 = gamma */
+#define VKAS_LOSS_DICE 1      /* dice.py:17-35: pred are probabilities; 1 - 2 sum(pg) / (sum p + sum g + eps) */
+#define VKAS_LOSS_L1 2        /* l1.py:19-47, smooth = False */
+#define VKAS_LOSS_SMOOTH_L1 3 /* l1.py:19-47, smooth = True: p0 = smooth_beta */
+#define VKAS_LOSS_L2 4        /* l2.py:18-34 */
+/* pred, gt, mask (nullable): n fp32 elements each.  mask == NULL: mean over n; else sum(e * mask) / (sum(mask) + eps)
+ * (dice: pred and gt are multiplied by the mask).  sums: 4 doubles kept for backward; loss: 1 float. */
+int vkas_elementwise_loss_fwd(int kind, const float* pred, const float* gt, const float* mask, long n, float p0, float p1,
+                              float eps, double* sums, float* loss, void* stream);
+int vkas_elementwise_loss_bwd(int kind, const float* pred, const float* gt, const float* mask, long n, float p0, float p1,
+                              float eps, const double* sums, const float* dloss, float* dpred, void* stream);
+/* F.cross_entropy(logits (rows, classes), target), mean over rows: cross_entropy_with_logits.py:16-19.
+ * hard = 0: target is (rows, classes) fp32 class probabilities; hard = 1: (rows,) int64 class indices in range. */
+int vkas_cross_entropy_fwd(const float* logits, const void* target, int hard, long rows, int classes, double* sums,
+                           float* loss, void* stream);
+int vkas_cross_entropy_bwd(const float* logits, const void* target, int hard, long rows, int classes, const float* dloss,
+                           float* dlogits, void* stream);
+
 /* ---- optimizer on the flat parameter / gradient buffers: train.py:468-478 ------------------------------ */
 /* sumsq (1 double, zeroed by the call) = sum g^2 */
 int vkas_l2norm_sq(const float* g, long n, double* sumsq, void* stream);

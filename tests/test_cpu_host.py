@@ -145,3 +145,57 @@ def test_bucket_layout_for_adaptive_scaling():
     assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])), 'buckets must tile the flat buffer'
     n_rough = sum(p.numel() for n, p in model.named_parameters() if n.startswith('rough_'))
     assert red.buckets['rough'].end - red.buckets['rough'].start >= n_rough
+
+
+def test_flat_buffers_touched_ranges_and_invalidation():
+    """Parameters that never got a gradient are left out of the AdamW launch ranges (torch.optim.AdamW skips
+    .grad is None); load_flat() drops the packed-weight cache (writes behind the version counter)."""
+    from vkit_ocr_model_adaptive_scaling_amd.training import FlatBuffers
+    from vkit_ocr_model_adaptive_scaling_amd import ops
+    m = torch.nn.ModuleDict({'a': torch.nn.Linear(5, 3), 'unused': torch.nn.Linear(3, 3), 'b': torch.nn.Linear(3, 7)})
+    fb = FlatBuffers(m.named_parameters())
+    assert fb.touched_ranges() == []
+    m['b'](m['a'](torch.ones(2, 5))).sum().backward()
+    a0, b0 = fb.offsets['a.weight'][0], fb.offsets['b.weight'][0]
+    u0 = fb.offsets['unused.weight'][0]
+    assert fb.touched_ranges() == [(a0, u0), (b0, fb.numel)]
+    fb.zero_grad()
+    assert fb.touched_ranges() == []
+    ops._PACK_CACHE[('sentinel', 0)] = None
+    epoch = ops._PACK_EPOCH[0]
+    fb.load_flat(torch.arange(fb.numel, dtype=torch.float32))
+    assert not ops._PACK_CACHE and ops._PACK_EPOCH[0] == epoch + 1
+    assert float(m['a'].weight.reshape(-1)[1]) == 1.0
+    with pytest.raises(ValueError):
+        fb.load_flat(torch.zeros(3))
+
+
+def test_loss_exports_and_shape_contract():
+    """loss_function/__init__.py:12-24 exports, and the shape contract the fused loss ops enforce before any kernel
+    indexes with the numbers (pure host logic: runs on CPU tensors)."""
+    from vkit_ocr_model_adaptive_scaling_amd import loss_function as L
+    from vkit_ocr_model_adaptive_scaling_amd import ops
+    for name in ('WeightedBceWithLogitsLossFunction', 'CrossEntropyWithLogitsLossFunction', 'FocalWithLogitsLossFunction',
+                 'L1LossFunction', 'L2LossFunction', 'WeightAdaptiveHeatmapRegressionLossFunction', 'DiceLossFunction',
+                 'AdaptiveScalingRoughLossFunctionConifg', 'AdaptiveScalingRoughLossFunction',
+                 'AdaptiveScalingPreciseLossFunctionConifg', 'AdaptiveScalingPreciseLossFunction'):
+        assert hasattr(L, name), name
+    f = L.FocalWithLogitsLossFunction()
+    assert (f.alpha, f.gamma, f.eps) == (0.25, 2, 1e-6)
+    l1 = L.L1LossFunction()
+    assert (l1.eps, l1.smooth, l1.smooth_beta) == (1e-6, False, 1.0)
+    assert L.DiceLossFunction().eps == 1e-6 and L.L2LossFunction().eps == 1e-6
+    with pytest.raises(NotImplementedError):
+        L.WeightedBceWithLogitsLossFunction()
+    with pytest.raises(RuntimeError, match='MI355X'):
+        L.L2LossFunction()(torch.zeros(4), torch.zeros(4))  # no CPU fallback
+    z = torch.zeros
+    ops._check_loss_maps('t', (z(2, 1, 8, 9), z(2, 1, 8, 9)), (1, 1), z(2, 4, 5), z(2, 4, 5), 2, 2)
+    with pytest.raises(ValueError):
+        ops._check_loss_maps('t', (z(2, 1, 8, 9), z(2, 2, 8, 9)), (1, 1), z(2, 4, 5), z(2, 4, 5), 2, 2)
+    with pytest.raises(ValueError):
+        ops._check_loss_maps('t', (z(2, 1, 8, 9),), (1,), z(3, 4, 5), z(3, 4, 5), 2, 2)  # batch mismatch
+    with pytest.raises(ValueError):
+        ops._check_loss_maps('t', (z(2, 1, 8, 9),), (1,), z(2, 4, 5), z(2, 4, 6), 2, 2)  # score map != mask
+    with pytest.raises(ValueError):
+        ops._check_loss_maps('t', (z(2, 1, 8, 9),), (1,), z(2, 7, 5), z(2, 7, 5), 2, 2)  # crop leaves the map

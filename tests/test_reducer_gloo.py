@@ -1,5 +1,11 @@
-"""World-size-2 gloo run (CPU) of the bucketed gradient reducer with the two-pass step pattern: rough-branch bucket
-reduced after backward #1, backbone buckets only armed for backward #2, result equals the mean of per-rank grads."""
+"""World-size-2 gloo runs (CPU) of the bucketed gradient reducer.
+
+* two-pass pattern (the reference's step order): rough-branch bucket reduced after backward #1, backbone buckets only
+  armed for backward #2, result equals the mean of per-rank grads;
+* merged pattern (what bench.py times, TwoPassStep(merge_backbone=True), training/ddp.py): every bucket armed for ONE
+  backward of rough_loss + precise_loss; branch buckets fire before the backbone buckets, backbone buckets in reverse
+  stage order, same mean gradient;
+* construction broadcasts rank 0's parameters (ranks are seeded differently on purpose)."""
 import os
 import socket
 
@@ -43,10 +49,15 @@ def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        torch.manual_seed(0)
+        torch.manual_seed(rank)  # different initial weights per rank: the reducer must broadcast rank 0's
         model = ToyTwoBranch()
         fb = FlatBuffers(model.named_parameters())
         red = BucketedGradReducer(fb, BUCKETS)
+        both = [torch.zeros_like(fb.flat_param) for _ in range(world)]
+        dist.all_gather(both, fb.flat_param)
+        assert all(torch.equal(both[0], b) for b in both), 'parameters differ across ranks after construction'
+        torch.manual_seed(0)
+        assert torch.equal(both[0], FlatBuffers(ToyTwoBranch().named_parameters()).flat_param), 'not rank 0\'s values'
         g = torch.Generator().manual_seed(100 + rank)
         xr, xp = torch.randn(5, 6, generator=g), torch.randn(5, 6, generator=g)
         scale = 0.5 / world
@@ -67,6 +78,21 @@ def _worker(rank, world, port, out):
             (ref.forward_precise(b).pow(2).sum() * scale).backward()
         for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
             assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7), n
+        # merged schedule: all buckets armed for one backward of the summed loss
+        fb.zero_grad()
+        red.launch_log.clear()
+        red.arm(['rough', 'precise', 'backbone1', 'backbone0'])
+        feats = model.features(torch.cat([xr, xp], 0))  # one backbone pass over both batches
+        out_r = model.rough_char_mask_head(torch.tanh(model.rough_neck(feats[:5])))
+        out_p = model.precise_char_prob_head(torch.tanh(model.precise_neck(feats[5:])))
+        (out_r.sum() * scale + out_p.pow(2).sum() * scale).backward()
+        assert sorted(red.launch_log[:2]) == ['precise', 'rough'] and red.launch_log[2:] == ['backbone1', 'backbone0'], \
+            red.launch_log
+        red.flush()
+        assert len(red.launch_log) == 4
+        for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7), ('merged', n)
+        assert fb.touched_ranges() == [(0, fb.numel)]
         # a bucket whose parameters never received a gradient is still reduced by flush()
         fb.zero_grad()
         red.launch_log.clear()

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'libvkas.so')
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_SCALE_RES, EPI_DGELU, EPI_ADD, EPI_PATCH, EPI_HEAD = range(7)
+LOSS_FOCAL, LOSS_DICE, LOSS_L1, LOSS_SMOOTH_L1, LOSS_L2 = range(5)
 
 
 class ConvGeom(Structure):
@@ -98,6 +99,10 @@ _SIGS = {
                                     POINTER(RoughLossCfg), _P, _P, _P, _P, _P]),
     'vkas_precise_loss_fwd': (c_int, [_P] * 11 + [c_int] * 8 + [POINTER(PreciseLossCfg), _P, _P, _P]),
     'vkas_precise_loss_bwd': (c_int, [_P] * 11 + [c_int] * 8 + [POINTER(PreciseLossCfg), _P, _P, _P, _P, _P, _P, _P]),
+    'vkas_elementwise_loss_fwd': (c_int, [c_int, _P, _P, _P, c_long, c_float, c_float, c_float, _P, _P, _P]),
+    'vkas_elementwise_loss_bwd': (c_int, [c_int, _P, _P, _P, c_long, c_float, c_float, c_float, _P, _P, _P, _P]),
+    'vkas_cross_entropy_fwd': (c_int, [_P, _P, c_int, c_long, c_int, _P, _P, _P]),
+    'vkas_cross_entropy_bwd': (c_int, [_P, _P, c_int, c_long, c_int, _P, _P, _P]),
     'vkas_l2norm_sq': (c_int, [_P, c_long, _P, _P]),
     'vkas_adamw_step': (c_int, [_P, _P, _P, _P, c_long, _P, c_float, c_float, c_float, c_float, c_float, c_float,
                                 c_float, c_int, _P]),

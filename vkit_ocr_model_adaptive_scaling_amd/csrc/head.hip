@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
           cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
           pdf = 0.39894228040143268f * __expf(-0.5f * u * u);
         }
-        const float act = cok ? u * cdf : 0.f;
+        const float act = cok ? (sizeof(T) == 2 ? fmaxf(u, -4.25f) : u) * cdf : 0.f;  // as gelu_t<T>
         float da = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

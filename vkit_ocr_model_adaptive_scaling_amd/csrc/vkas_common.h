@@ -106,8 +106,10 @@ __device__ __forceinline__ float dgelu_f(float x) {
 }
 
 // bf16-storage variants.  Phi(x) = 0.5 + x * P(x^2) on |x| <= 4.25 (degree-8 near-minimax fit, fp32 Horner; x clamped
-// outside, where Phi is within 1.1e-5 of 0 / 1): |Phi error| <= 1.3e-5, |gelu error| <= 5e-5 - below half a bf16 ulp
-// for every |gelu(x)| > 0.03 - with 12 plain VALU operations and no transcendental (the erf / exp form cost as much as
+// outside, where Phi is within 1.1e-5 of 0 / 1): |Phi error| <= 1.3e-5.  gelu(x) = max(x, -4.25) * Phi: the factor is
+// clamped on the negative side too, so the left tail stays at -4.5e-5 instead of growing like 1.07e-5 * x (exact
+// gelu -> 0 there); |gelu error| <= 5e-5 everywhere - below half a bf16 ulp for every |gelu(x)| > 0.03 - with 13 plain
+// VALU operations and no transcendental (the erf / exp form cost as much as
 // the MFMAs of a short-K layer GEMM in its epilogue).  phi(x) needs one v_exp_f32 and is only computed when the
 // derivative is wanted.  fp32 storage keeps the exact forms.
 __device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& pdf_x) {
@@ -130,7 +132,7 @@ template <> __device__ __forceinline__ float gelu_t<float>(float x) { return gel
 template <> __device__ __forceinline__ float gelu_t<bf16_t>(float x) {
   float cdf, pdf;
   gelu_parts_fast(x, cdf, pdf);
-  return x * cdf;
+  return fmaxf(x, -4.25f) * cdf;
 }
 template <typename T> __device__ __forceinline__ float dgelu_t(float x);
 template <> __device__ __forceinline__ float dgelu_t<float>(float x) { return dgelu_f(x); }

@@ -865,6 +865,22 @@ class Softplus(Function):
         return dx
 
 
+def _check_loss_maps(who, preds, channels, gt_mask, gt_score, up, left):
+    """Shape / device contract of the dense losses (loss_function/adaptive_scaling.py:67-86,213-231): every tensor on
+    the GPU, predictions (B, c, H, W), targets (B, CH, CW) with the crop inside the map.  The kernels index with these
+    numbers, so a mismatch must raise here instead of reading out of bounds."""
+    B, _, H, W = preds[0].shape
+    for t, c in zip(preds, channels):
+        if tuple(t.shape) != (B, c, H, W):
+            raise ValueError(f'{who}: prediction must be ({B}, {c}, {H}, {W}), got {tuple(t.shape)}')
+    if gt_mask.dim() != 3 or gt_mask.shape[0] != B or gt_score.shape != gt_mask.shape:
+        raise ValueError(f'{who}: targets must be (B={B}, CH, CW) and equal, got {tuple(gt_mask.shape)} / '
+                         f'{tuple(gt_score.shape)}')
+    _, CH, CW = gt_mask.shape
+    if up < 0 or left < 0 or up + CH > H or left + CW > W:
+        raise ValueError(f'{who}: core box (up={up}, left={left}, {CH}x{CW}) does not fit the {H}x{W} map')
+
+
 class RoughLoss(Function):
     """AdaptiveScalingRoughLossFunction.__call__ (loss_function/adaptive_scaling.py:53-131), default-active terms."""
 
@@ -873,6 +889,7 @@ class RoughLoss(Function):
         _require_cuda(mask_feat, height_feat, gt_mask, gt_score)
         mask_feat, height_feat = mask_feat.contiguous().float(), height_feat.contiguous().float()
         gt_mask, gt_score = gt_mask.contiguous().float(), gt_score.contiguous().float()
+        _check_loss_maps('RoughLoss', (mask_feat, height_feat), (1, 1), gt_mask, gt_score, up, left)
         B, _, H, W = mask_feat.shape
         _, CH, CW = gt_mask.shape
         sums = torch.empty((8,), dtype=torch.float64, device=mask_feat.device)
@@ -902,14 +919,27 @@ class PreciseLoss(Function):
 
     @staticmethod
     def forward(ctx, prob, offset, angle, dist, gt_score, gt_mask, py, px, gt_off, gt_ang, gt_dist, up, left, cfg):
-        _require_cuda(prob, offset, angle, dist)
+        _require_cuda(prob, offset, angle, dist, gt_score, gt_mask, py, px, gt_off, gt_ang, gt_dist)
         f = lambda t: t.contiguous().float()
         prob, offset, angle, dist = f(prob), f(offset), f(angle), f(dist)
         gt_score, gt_mask, gt_off, gt_ang, gt_dist = f(gt_score), f(gt_mask), f(gt_off), f(gt_ang), f(gt_dist)
         py, px = py.contiguous().long(), px.contiguous().long()
+        _check_loss_maps('PreciseLoss', (prob, offset, angle, dist), (1, 2, 4, 4), gt_mask, gt_score, up, left)
         B, _, H, W = prob.shape
         _, CH, CW = gt_mask.shape
+        if py.dim() != 2 or py.shape[0] != B or px.shape != py.shape:
+            raise ValueError(f'PreciseLoss: label points must be (B={B}, P), got {tuple(py.shape)} / {tuple(px.shape)}')
         P = py.shape[1]
+        for name, t, last in (('up_left_offsets', gt_off, 2), ('corner_angles', gt_ang, 4), ('corner_distances', gt_dist, 3)):
+            if tuple(t.shape) != (B, P, last):
+                raise ValueError(f'PreciseLoss: {name} must be ({B}, {P}, {last}), got {tuple(t.shape)}')
+        if P > 0:
+            # the reference's advanced indexing raises on out-of-range label points (and wraps negative ones); a corrupt
+            # batch must not train on clamped pixels: one fused min/max + a single host read
+            lim = torch.stack([py.min(), py.max() - (H - 1), px.min(), px.max() - (W - 1)])
+            lo_y, hi_y, lo_x, hi_x = (int(v) for v in lim.tolist())
+            if lo_y < 0 or hi_y > 0 or lo_x < 0 or hi_x > 0:
+                raise IndexError(f'PreciseLoss: label points outside the {H}x{W} map')
         sums = torch.empty((8,), dtype=torch.float64, device=prob.device)
         loss = torch.empty((), dtype=_FLOAT, device=prob.device)
         check(lib.vkas_precise_loss_fwd(_p(prob), _p(offset), _p(angle), _p(dist), _p(gt_score), _p(gt_mask), _p(py),
@@ -933,3 +963,78 @@ class PreciseLoss(Function):
                                         ctypes.byref(cfg), _p(sums), _p(dloss), _p(dp), _p(do), _p(da), _p(dd),
                                         _stream()), 'precise_loss_bwd')
         return (dp, do, da, dd) + (None,) * 10
+
+
+class ElementwiseLoss(Function):
+    """The mean-/masked-mean-type primitive losses and dice (loss_function/{focal_with_logits,dice,l1,l2}.py) as one
+    reduction kernel + finalize; gradient for ``pred`` only (targets and masks are data)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, mask, kind: int, p0: float, p1: float, eps: float):
+        _require_cuda(pred, gt, mask)
+        if gt.shape != pred.shape or (mask is not None and mask.shape != pred.shape):
+            raise ValueError(f'loss: pred {tuple(pred.shape)}, gt {tuple(gt.shape)}'
+                             + (f', mask {tuple(mask.shape)}' if mask is not None else '') + ' must have equal shapes')
+        shape = pred.shape
+        pred, gt = pred.contiguous().float(), gt.contiguous().float()
+        mask = None if mask is None else mask.contiguous().float()
+        sums = torch.empty((4,), dtype=torch.float64, device=pred.device)
+        loss = torch.empty((), dtype=_FLOAT, device=pred.device)
+        check(lib.vkas_elementwise_loss_fwd(kind, _p(pred), _p(gt), _p(mask), pred.numel(), p0, p1, eps, _p(sums), _p(loss),
+                                            _stream()), 'elementwise_loss_fwd')
+        ctx.save_for_backward(pred, gt, mask if mask is not None else torch.empty(0, device=pred.device), sums)
+        ctx.cfg = (kind, p0, p1, eps, mask is not None, shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        pred, gt, mask, sums = ctx.saved_tensors
+        kind, p0, p1, eps, has_mask, shape = ctx.cfg
+        dpred = torch.empty_like(pred)
+        dloss = dloss.contiguous().float()
+        check(lib.vkas_elementwise_loss_bwd(kind, _p(pred), _p(gt), _p(mask) if has_mask else None, pred.numel(), p0, p1, eps,
+                                            _p(sums), _p(dloss), _p(dpred), _stream()), 'elementwise_loss_bwd')
+        return dpred.view(shape), None, None, None, None, None, None
+
+
+class CrossEntropy(Function):
+    """F.cross_entropy on (rows, classes) logits with class-probability targets of the same shape or int64 class
+    indices (loss_function/cross_entropy_with_logits.py:16-19); mean over rows."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        _require_cuda(logits, target)
+        if logits.dim() != 2:
+            raise ValueError(f'cross entropy: logits must be (rows, classes), got {tuple(logits.shape)}')
+        rows, classes = logits.shape
+        hard = not target.is_floating_point()
+        if hard:
+            if tuple(target.shape) != (rows,):
+                raise ValueError(f'cross entropy: class-index target must be ({rows},), got {tuple(target.shape)}')
+            target = target.contiguous().long()
+            if rows > 0:
+                lo, hi = (int(v) for v in torch.stack([target.min(), target.max()]).tolist())
+                if lo < 0 or hi >= classes:
+                    raise IndexError(f'cross entropy: target class outside [0, {classes})')
+        else:
+            if target.shape != logits.shape:
+                raise ValueError(f'cross entropy: probability target must be {tuple(logits.shape)}, got {tuple(target.shape)}')
+            target = target.contiguous().float()
+        logits = logits.contiguous().float()
+        sums = torch.empty((4,), dtype=torch.float64, device=logits.device)
+        loss = torch.empty((), dtype=_FLOAT, device=logits.device)
+        check(lib.vkas_cross_entropy_fwd(_p(logits), _p(target), int(hard), rows, classes, _p(sums), _p(loss), _stream()),
+              'cross_entropy_fwd')
+        ctx.save_for_backward(logits, target)
+        ctx.hard = hard
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, target = ctx.saved_tensors
+        rows, classes = logits.shape
+        d = torch.empty_like(logits)
+        dloss = dloss.contiguous().float()
+        check(lib.vkas_cross_entropy_bwd(_p(logits), _p(target), int(ctx.hard), rows, classes, _p(dloss), _p(d), _stream()),
+              'cross_entropy_bwd')
+        return d, None

@@ -55,6 +55,9 @@ class BucketedGradReducer:
             raise ValueError(f'parameters without a bucket: {missing[:4]}...')
         self._works: List = []
         self.launch_log: List[str] = []  # bucket names in launch order (inspected by tests)
+        # like DistributedDataParallel at construction: every rank starts from rank 0's parameters, whatever its seed
+        if self.world_size > 1:
+            flat.broadcast_params(src=0, group=process_group)
         for n, p in zip(flat.names, flat.params):
             p.register_post_accumulate_grad_hook(self._make_hook(n))
 
@@ -160,4 +163,7 @@ class TwoPassStep:
             r.flush()
         self.optimizer.step(lr=lr)
         self.optimizer.zero_grad()
+        # the values the reference logs are loss / 2 (train.py:413-415,451-453): undo the 1 / world pre-scaling
+        if self.world > 1:
+            return rough_loss.detach() * self.world, precise_loss.detach() * self.world
         return rough_loss.detach(), precise_loss.detach()

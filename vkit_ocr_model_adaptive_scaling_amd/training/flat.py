@@ -4,7 +4,13 @@ All parameters of a model become views into one fp32 buffer and all ``.grad`` te
 (registration order, each tensor aligned to 16 bytes).  The gradient buffer is what RCCL all-reduces (contiguous
 ranges = buckets) and what the fused clip + AdamW kernels walk; autograd accumulates into the views in place, so the
 two backward passes of a step (train.py:416,454) sum without extra copies.  Device-agnostic (the CPU/gloo tests of the
-reducer use it too)."""
+reducer use it too).
+
+Writing parameters.  The HIP ops cache packed (bf16, GEMM-layout) copies of the weights between the uses of one
+parameter value (ops._PACK_CACHE) and recognise a change by the parameter's autograd version counter.  Writes that go
+around that counter - anything through ``flat_param`` (checkpoint load, rank-0 broadcast) or through ``p.data`` (EMA
+swaps, manual init) - must be followed by ``notify_params_changed()`` (= ``ops.invalidate_packed_params()``);
+``load_flat`` / ``broadcast_params`` below and ``FlatAdamW.step`` do it themselves."""
 from typing import Dict, Iterable, List, Tuple
 
 import torch
@@ -41,9 +47,55 @@ class FlatBuffers:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.flat_grad[start:start + size].view(p.shape)
+        # which parameters received a gradient since the last zero_grad(): torch.optim.AdamW (train.py:287-298) skips
+        # parameters whose .grad is None; here .grad is a persistent view, so the hook keeps the equivalent record
+        self.touched = bytearray(len(self.params))
+        for i, p in enumerate(self.params):
+            p.register_post_accumulate_grad_hook(self._touch_hook(i))
+
+    def _touch_hook(self, i: int):
+        def hook(_param):
+            self.touched[i] = 1
+        return hook
+
+    def touched_ranges(self) -> List[Tuple[int, int]]:
+        """Maximal contiguous [start, end) element ranges of parameters that got a gradient since zero_grad()."""
+        out: List[Tuple[int, int]] = []
+        for i, n in enumerate(self.names):
+            if not self.touched[i]:
+                continue
+            start, size = self.offsets[n]
+            end = start + (size + ALIGN - 1) // ALIGN * ALIGN
+            if out and out[-1][1] == start:
+                out[-1] = (out[-1][0], end)
+            else:
+                out.append((start, end))
+        return out
+
+    @staticmethod
+    def notify_params_changed():
+        """Drop every packed weight copy the HIP ops cached: call after writing parameters behind autograd's back."""
+        from .. import ops
+        ops.invalidate_packed_params()
+
+    def load_flat(self, values: torch.Tensor):
+        """Overwrite all parameters from a flat fp32 tensor in this buffer's layout (checkpoint restore)."""
+        if values.numel() != self.numel:
+            raise ValueError(f'expected {self.numel} elements, got {values.numel()}')
+        with torch.no_grad():
+            self.flat_param.copy_(values.reshape(-1))
+        self.notify_params_changed()
+
+    def broadcast_params(self, src: int = 0, group=None):
+        """Make every rank hold rank ``src``'s parameters (what DistributedDataParallel does at construction)."""
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.broadcast(self.flat_param, src=src, group=group)
+        self.notify_params_changed()
 
     def zero_grad(self):
         self.flat_grad.zero_()
+        self.touched = bytearray(len(self.params))
         for n, p in zip(self.names, self.params):  # re-attach views if someone set .grad to None
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * self.offsets[n][0]:
                 start, size = self.offsets[n]

@@ -29,6 +29,12 @@ def cosine_warm_restarts_lr(epoch: float, base_lr: float, eta_min: float, t_0: i
     return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * t_cur / t_i)) / 2
 
 
+def all_or_none(flags: bytearray):
+    """True if every flag is set, False if none is, None for a mix."""
+    n = sum(flags)
+    return True if n == len(flags) else (False if n == 0 else None)
+
+
 class FlatAdamW:
     """AdamW(lr 8e-4, betas (0.9, 0.999), wd 0.01) with clip_grad_norm_(max_norm 2.5) (train.py:72-80,468-478)."""
 
@@ -61,10 +67,16 @@ class FlatAdamW:
         if self.max_grad_norm is not None:
             check(lib.vkas_l2norm_sq(ptr(f.flat_grad), f.numel, ptr(self.sumsq), st), 'l2norm_sq')
             sumsq = ptr(self.sumsq)
-        check(lib.vkas_adamw_step(ptr(f.flat_param), ptr(f.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), f.numel,
-                                  sumsq, float(self.max_grad_norm or 0.0), float(grad_scale),
-                                  float(self.lr if lr is None else lr), self.betas[0], self.betas[1], self.eps,
-                                  self.weight_decay, self.step_count, st), 'adamw_step')
+        # torch.optim.AdamW leaves parameters without a gradient untouched (no decay, no moment update): e.g. the
+        # precise mask head under precise_enable_char_mask_head, which forward_precise never runs.  One launch per
+        # contiguous run of parameters that did receive a gradient (normally the whole buffer).
+        ranges = f.touched_ranges() if all_or_none(f.touched) is None else ([(0, f.numel)] if all_or_none(f.touched) else [])
+        for start, end in ranges:
+            off = lambda t: ctypes.c_void_p(t.data_ptr() + 4 * start)
+            check(lib.vkas_adamw_step(off(f.flat_param), off(f.flat_grad), off(self.exp_avg), off(self.exp_avg_sq),
+                                      end - start, sumsq, float(self.max_grad_norm or 0.0), float(grad_scale),
+                                      float(self.lr if lr is None else lr), self.betas[0], self.betas[1], self.eps,
+                                      self.weight_decay, self.step_count, st), 'adamw_step')
         ops.invalidate_packed_params()  # parameters changed behind autograd's version counters
 
     def grad_norm(self) -> float:
