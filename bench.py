@@ -250,7 +250,7 @@ def main():
             pmc = json.load(open(pmc_path)).get(dom)
             if pmc:
                 traffic = pmc['bytes_per_launch']
-        is_gemm = lambda k: k.startswith(('gemm_', 'conv3x3_'))  # the depthwise / resize launches are timed too (HBM roofs)
+        is_gemm = lambda k: k.startswith(('gemm_', 'conv3x3_', 'mlp_chain_'))  # the depthwise / resize launches are timed too (HBM roofs)
         all_gemm_flops = sum(v['flops'] for k, v in summ.items() if is_gemm(k))
         all_gemm_ms = sum(v['ms'] for k, v in summ.items() if is_gemm(k))
         if summ:

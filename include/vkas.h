@@ -96,9 +96,17 @@ typedef struct vkas_epilogue {
  * mode 2: dgrad operand of a patchify conv: out[(ky,kx,c)][n] = w[n][c][ky][kx] (rows KH*KW*Cp, cols Np). */
 int vkas_pack_conv_weight(const float* w, void* out, int N, int C, int KH, int KW, int Np, int Cp, int mode,
                           int dtype, void* stream);
+/* the same for one of several convolutions that share their input and are packed side by side (the heads of a pass,
+ * adaptive_scaling.py:150-152,163-170): fills output channels [n_off, n_off + Np) of an operand with Nt output channels
+ * in total; mode 0 (forward) or 1 (dgrad). */
+int vkas_pack_conv_weight_slice(const float* w, void* out, int N, int C, int KH, int KW, int Np, int Cp, int mode,
+                                int n_off, int Nt, int dtype, void* stream);
 /* gw (Np, KH, KW, Cp) fp32 [wgrad output] -> grad (N,C,KH,KW) fp32, grad += (accumulate != 0) or = */
 int vkas_unpack_conv_wgrad(const float* gw, float* grad, int N, int C, int KH, int KW, int Np, int Cp,
                            int accumulate, void* stream);
+/* dst[k][0..n[k]) += src[k][0..n[k]) for count <= 16 fp32 vectors in one launch: the small per-parameter gradients of a
+ * layer (bias, LayerNorm affine, block_scale; what autograd's AccumulateGrad does one launch per tensor) */
+int vkas_accumulate_many(int count, const float* const* src, float* const* dst, const int* n, void* stream);
 /* v (n) fp32 -> out (np) fp32 zero padded (bias, LayerNorm affine, block_scale) */
 int vkas_pad_vector(const float* v, float* out, int n, int np, void* stream);
 /* depthwise weight (C,1,7,7) fp32 -> (49, Cp) fp32; flip != 0 rotates the taps by 180 degrees (dgrad operand) */
@@ -120,6 +128,28 @@ int vkas_conv_gemm_fwd(const void* x, const vkas_conv_geom* g, const void* Bw, i
  * fp32 atomics. */
 int vkas_conv_gemm_wgrad(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
                          float* gb, int dtype, void* stream);
+/* the same with A(m,k) = gelu(x(m,k)): weight gradient of the second MLP Linear when the forward kept only the
+ * pre-activation h (vkas_mlp_chain_fwd): backward of convnext.py:34-35 */
+int vkas_conv_gemm_wgrad_gelu(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
+                              float* gb, int dtype, void* stream);
+
+/* ---- fused ConvNeXt MLP (convnext.py:33-35,54-58), C % 8 == 0, C <= 256, bf16 --------------------------------------
+ * Linear(C,4C) -> GELU -> Linear(4C,C) -> layer scale -> stochastic depth -> residual as one kernel per direction; the
+ * (M, 4C) activation is written once (h, for backward) and never read back between the two matrix products.
+ * Weights are consumed as a packed, pre-swizzled LDS image: vkas_mlp_chain_image_elems(C) elements of `dtype`, built by
+ * vkas_mlp_chain_pack from w1 (4C, C) / w2 (C, 4C) fp32 in the reference layout; mode 0 = forward image, 1 = backward
+ * image (transposed roles; b1 may be NULL).  image_elems returns 0 when C is not covered. */
+size_t vkas_mlp_chain_image_elems(int C);
+int vkas_mlp_chain_pack(const float* w1, const float* w2, const float* b1, int C, int mode, void* img, int dtype,
+                        void* stream);
+/* h = yn W1^T + b1 (stored; b1 (4C) travels inside the forward image); z = gelu(h) W2^T + b2 (stored);
+ * out = x + rowscale[m / rows_per_image] * colscale * z.  b2 (C), colscale (C) fp32; rowscale (images) fp32 or NULL. */
+int vkas_mlp_chain_fwd(const void* yn, long ldyn, const void* img, const float* b2, const void* x, long ldx,
+                       const float* colscale, const float* rowscale, int rows_per_image, void* h, long ldh, void* z,
+                       long ldz, void* out, long ldo, long M, int C, int dtype, void* stream);
+/* dh = (dz W2) * gelu'(h) (stored, operand of the W1 weight gradient); dyn = dh W1.  img_t = the mode-1 image. */
+int vkas_mlp_chain_bwd(const void* dz, long lddz, const void* img_t, const void* h, long ldh, void* dh, long lddh,
+                       void* dyn, long lddyn, long M, int C, int dtype, void* stream);
 /* profiling aid: tile configuration a bf16 call of these sizes runs.  fwd (wgrad == 0): 1 = 128x128 (4 waves), else the
  * N extent 128 / 192 / 224 of the 256-row 8-wave tile; wgrad: N extent 128 (4 waves) or 192 / 224 (8 waves); 0 when the
  * plain fp32-FMA kernels are forced (VKAS_GEMM=simple). */

@@ -294,7 +294,9 @@ def test_packed_weight_cache_invalidation():
     with torch.no_grad():
         y0 = m(x)[0].clone()
         assert torch.equal(m(x)[0], y0)
-        m.stem[0].weight.mul_(2.0)              # in-place through autograd's view: version counter moves, no call needed
+        # in-place through autograd's view: the version counter moves, no call needed (a pure rescale would vanish in
+        # the LayerNorm that follows every convolution of this model, hence the random direction)
+        m.stem[0].weight.add_(torch.randn_like(m.stem[0].weight) * 0.05)
         y1 = m(x)[0].clone()
         assert not torch.equal(y1, y0)
         fb.flat_param.mul_(0.5)                 # behind the counter

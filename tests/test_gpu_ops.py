@@ -176,7 +176,10 @@ torch.save({'y': y.float().cpu(), 'gx': x.grad.float().cpu(), 'gw': w.grad.cpu()
 
 # --------------------------------------------------------------------------------------------- dwconv / layer
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
-@pytest.mark.parametrize('shape', [(2, 24, 19, 37), (1, 16, 8, 8), (2, 96, 40, 33), (1, 40, 5, 3)])
+@pytest.mark.parametrize('shape', [(2, 24, 19, 37), (1, 16, 8, 8), (2, 96, 40, 33), (1, 40, 5, 3),
+                                   # every instantiation of the fused MLP kernel (C <= 32 / 64 / 96 / 128 / 192 / 256) and one
+                                   # width beyond it (two-GEMM path)
+                                   (1, 64, 7, 9), (2, 128, 12, 9), (1, 192, 9, 7), (1, 256, 6, 5), (1, 264, 4, 4)])
 def test_convnext_layer(shape, dtype):
     """Whole ConvNextBlockLayer (dw7x7, LN, MLP, layer scale, stochastic depth mask, residual) fwd + bwd."""
     ops = ops_mod()
@@ -210,6 +213,39 @@ def test_convnext_layer(shape, dtype):
         assert r < (1.5e-2 if wide else 5e-5), (k, r)
     r = rel_err(from_act(xa.grad, C), xr.grad)
     assert r < (1.5e-2 if wide else 5e-5), ('dx', r)
+
+
+@pytest.mark.parametrize('C', [16, 96, 192])
+def test_mlp_chain_matches_two_gemm_path(C):
+    """The fused MLP kernels against the two-GEMM layer path they replace (same bf16 inputs; the two differ only in
+    where fp32 values are rounded to bf16): outputs and every gradient, ragged M (not a multiple of the 256/128-row tile),
+    dropped sample."""
+    ops = ops_mod()
+    torch.manual_seed(C)
+    B, H, W = 3, 37, 29
+    x = torch.randn(B, H, W, C, device='cuda').to(torch.bfloat16)
+    names = ['dw_w', 'dw_b', 'ln_g', 'ln_b', 'w1', 'b1', 'w2', 'b2', 'scale']
+    base = [torch.randn(C, 1, 7, 7) * 0.15, torch.randn(C) * 0.1, 1 + torch.randn(C) * 0.1, torch.randn(C) * 0.1,
+            (torch.randn(4 * C, C) / math.sqrt(C)).to(torch.bfloat16).float(), torch.randn(4 * C) * 0.1,
+            (torch.randn(C, 4 * C) * 0.5 / math.sqrt(C)).to(torch.bfloat16).float(), torch.randn(C) * 0.1,
+            1 + torch.randn(C, 1, 1) * 0.2]
+    mask = torch.tensor([1.25, 0.0, 1.0], device='cuda')
+    cot = torch.randn(B, H, W, C, device='cuda').to(torch.bfloat16)
+    res = {}
+    for chain in (True, False):
+        ops._NO_CHAIN = not chain
+        try:
+            ps = [t.clone().cuda().requires_grad_(True) for t in base]
+            xa = x.clone().requires_grad_(True)
+            assert ops.mlp_chain_eligible(xa, C) == chain
+            y = ops.ConvNextLayer.apply(xa, *ps, mask)
+            y.backward(cot)
+            res[chain] = [y.detach()] + [xa.grad] + [p.grad for p in ps]
+        finally:
+            ops._NO_CHAIN = False
+    for name, a, b in zip(['out', 'dx'] + names, res[True], res[False]):
+        assert rel_err(a, b) < 1.5e-2, (name, rel_err(a, b))
+    assert float(res[True][0][1].float().sub(x[1].float()).abs().max()) == 0.0, 'dropped sample must pass through'
 
 
 # ------------------------------------------------------------------------------------------------- LayerNorm
@@ -566,6 +602,32 @@ def test_clip_adamw_matches_torch():
 
 
 # ------------------------------------------------------------------------------------------ fused head tail
+def test_adamw_skips_parameters_without_gradient():
+    """torch.optim.AdamW leaves parameters whose .grad is None untouched (no weight decay, no moment update) - e.g. the
+    precise mask head under precise_enable_char_mask_head, which forward_precise never runs."""
+    from vkit_ocr_model_adaptive_scaling_amd.training import FlatAdamW, FlatBuffers
+    torch.manual_seed(5)
+    mk = lambda: torch.nn.ModuleDict({'a': torch.nn.Linear(16, 8), 'unused': torch.nn.Linear(8, 8), 'b': torch.nn.Linear(8, 4)})
+    m, r = mk().cuda(), mk().cuda()
+    r.load_state_dict(m.state_dict())
+    fb = FlatBuffers(m.named_parameters())
+    opt = FlatAdamW(None, lr=1e-2, weight_decay=0.1, max_grad_norm=1.0, flat=fb)
+    ropt = torch.optim.AdamW(r.parameters(), lr=1e-2, weight_decay=0.1)
+    x = torch.randn(5, 16, device='cuda')
+    for _ in range(3):
+        m['b'](m['a'](x)).pow(2).sum().backward()
+        opt.step()
+        opt.zero_grad()
+        r['b'](r['a'](x)).pow(2).sum().backward()
+        torch.nn.utils.clip_grad_norm_(r.parameters(), 1.0)
+        ropt.step()
+        ropt.zero_grad(set_to_none=True)
+    for (n, p), (_, q) in zip(m.named_parameters(), r.named_parameters()):
+        assert rel_err(p, q) < 2e-6, n
+    s0, k0 = fb.offsets['unused.weight']
+    assert float(opt.exp_avg[s0:s0 + k0].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('hw', [(128, 136), (66, 256)], ids=['generic', 'rowslab'])
 @pytest.mark.parametrize('chans', [((40, 33), (1, 4)), ((192, 193, 194, 194), (1, 2, 4, 4)), ((96,), (3,))])
 def test_heads_fused_matches_unfused_and_fp64(chans, hw):
@@ -594,14 +656,9 @@ def test_heads_fused_matches_unfused_and_fp64(chans, hw):
     # fused op
     xa = to_act(x, dtype).requires_grad_(True)
     dev = [[t.float().cuda().requires_grad_(True) for t in (w, b, g, bt, wp, bp)] for (w, b), (g, bt, wp, bp) in zip(convs, tails)]
-    w_parts, b_parts, fused = [], [], []
-    for (w, b, g, bt, wp, bp), c in zip(dev, cs):
-        pad = (c + 7) // 8 * 8 - c
-        w_parts.append(F.pad(w, (0, 0, 0, 0, 0, 0, 0, pad)))
-        b_parts.append(F.pad(b, (0, pad)))
-        fused.extend([g, bt, wp, bp])
+    fused = [t for head in dev for t in head]  # per head: conv weight, conv bias, gamma, beta, wproj, bproj
     assert ops.HeadsFused.eligible(xa, cs, ocs)
-    outs = ops.HeadsFused.apply(xa, torch.cat(w_parts, 0), torch.cat(b_parts, 0), *fused)
+    outs = ops.HeadsFused.apply(xa, *fused)
     loss = 0
     for o, oc, r, c in zip(outs, ocs, ref_outs, cots):
         assert tuple(o.shape) == (B, H, W, 8) and o.dtype == torch.float32

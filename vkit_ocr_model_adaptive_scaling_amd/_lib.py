@@ -60,7 +60,9 @@ _SIGS = {
     'vkas_last_error': (c_char_p, []),
     'vkas_abi_version': (c_int, []),
     'vkas_pack_conv_weight': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'vkas_pack_conv_weight_slice': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'vkas_unpack_conv_wgrad': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'vkas_accumulate_many': (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), _P]),
     'vkas_pad_vector': (c_int, [_P, _P, c_int, c_int, _P]),
     'vkas_pack_dw_weight': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'vkas_unpack_dw_wgrad': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
@@ -69,6 +71,12 @@ _SIGS = {
     'vkas_nchw_f32_to_nhwc': (c_int, [_P, _P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'vkas_conv_gemm_fwd': (c_int, [_P, POINTER(ConvGeom), _P, c_int, POINTER(Epilogue), c_int, _P]),
     'vkas_conv_gemm_wgrad': (c_int, [_P, POINTER(ConvGeom), _P, c_long, c_int, _P, _P, c_int, _P]),
+    'vkas_conv_gemm_wgrad_gelu': (c_int, [_P, POINTER(ConvGeom), _P, c_long, c_int, _P, _P, c_int, _P]),
+    'vkas_mlp_chain_image_elems': (c_size_t, [c_int]),
+    'vkas_mlp_chain_pack': (c_int, [_P, _P, _P, c_int, c_int, _P, c_int, _P]),
+    'vkas_mlp_chain_fwd': (c_int, [_P, c_long, _P, _P, _P, c_long, _P, _P, c_int, _P, c_long, _P, c_long, _P, c_long,
+                                   c_long, c_int, c_int, _P]),
+    'vkas_mlp_chain_bwd': (c_int, [_P, c_long, _P, _P, c_long, _P, c_long, _P, c_long, c_long, c_int, c_int, _P]),
     'vkas_conv_gemm_tile': (c_int, [c_int, c_long, c_int, c_int]),
     'vkas_conv_gemm_kernel_id': (c_int, [c_int, POINTER(ConvGeom), c_int, c_long, c_int]),
     'vkas_colsum': (c_int, [_P, c_long, c_long, c_int, _P, c_int, _P, c_size_t, c_int, _P]),

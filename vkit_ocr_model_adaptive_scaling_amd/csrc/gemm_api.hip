@@ -5,9 +5,9 @@
 #include "gemm_parts.h"
 
 int vkas_gemm_nt_simple(const void*, const vkas_conv_geom*, const void*, int, const vkas_epilogue*, int, hipStream_t);
-int vkas_gemm_tn_simple(const void*, const vkas_conv_geom*, const void*, long, int, float*, float*, int, hipStream_t);
+int vkas_gemm_tn_simple(const void*, const vkas_conv_geom*, const void*, long, int, float*, float*, int, int, hipStream_t);
 int vkas_gemm_nt_mfma_bf16(const void*, const vkas_conv_geom*, const void*, int, const vkas_epilogue*, hipStream_t);
-int vkas_gemm_tn_mfma_bf16(const void*, const vkas_conv_geom*, const void*, long, int, float*, float*, hipStream_t);
+int vkas_gemm_tn_mfma_bf16(const void*, const vkas_conv_geom*, const void*, long, int, float*, float*, int, hipStream_t);
 
 int vkas_gemm_nt_tile_choice(long M, int Np);
 int vkas_gemm_tn_tile_choice(long M, int Np, int K);
@@ -125,14 +125,25 @@ extern "C" int vkas_conv_gemm_kernel_id(int wgrad, const vkas_conv_geom* g, int 
   return choice;
 }
 
+static int conv_gemm_wgrad(const char* who, const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np,
+                           float* gw, float* gb, int x_gelu, int dtype, void* stream) {
+  int rc = vkas_check_geom(who, x, g, Np);
+  if (rc) return rc;
+  VKAS_CHECK(dy && vkas_aligned16(dy) && lddy >= Np && lddy % 8 == 0, "%s: bad dy (lddy=%ld)", who, lddy);
+  VKAS_CHECK(gw, "%s: null gw", who);
+  if (dtype == VKAS_BF16 && !force_simple())
+    return vkas_gemm_tn_mfma_bf16(x, g, dy, lddy, Np, gw, gb, x_gelu, vkas_stream(stream));
+  return vkas_gemm_tn_simple(x, g, dy, lddy, Np, gw, gb, x_gelu, dtype, vkas_stream(stream));
+}
+
 extern "C" int vkas_conv_gemm_wgrad(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np,
                                     float* gw, float* gb, int dtype, void* stream) {
-  int rc = vkas_check_geom("vkas_conv_gemm_wgrad", x, g, Np);
-  if (rc) return rc;
-  VKAS_CHECK(dy && vkas_aligned16(dy) && lddy >= Np && lddy % 8 == 0, "vkas_conv_gemm_wgrad: bad dy (lddy=%ld)", lddy);
-  VKAS_CHECK(gw, "vkas_conv_gemm_wgrad: null gw");
-  if (dtype == VKAS_BF16 && !force_simple()) return vkas_gemm_tn_mfma_bf16(x, g, dy, lddy, Np, gw, gb, vkas_stream(stream));
-  return vkas_gemm_tn_simple(x, g, dy, lddy, Np, gw, gb, dtype, vkas_stream(stream));
+  return conv_gemm_wgrad("vkas_conv_gemm_wgrad", x, g, dy, lddy, Np, gw, gb, 0, dtype, stream);
+}
+
+extern "C" int vkas_conv_gemm_wgrad_gelu(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np,
+                                         float* gw, float* gb, int dtype, void* stream) {
+  return conv_gemm_wgrad("vkas_conv_gemm_wgrad_gelu", x, g, dy, lddy, Np, gw, gb, 1, dtype, stream);
 }
 
 // ---- column sums ------------------------------------------------------------------------------------

@@ -681,7 +681,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int mbase, int col
 // channels x (WK*TK*16) K columns and walks its M split 64 rows at a time.  LDS tiles stay [row][col] with rows
 // padded by 16 elements (row pitch = odd multiple of 32 B => the 8 rows a half-wave touches in one transposing
 // read sit on distinct bank groups).
-template <int WN, int WK, int TNn, int TK, bool BUF>
+// XG: the x operand is gelu(x) (the W2 weight gradient of the fused ConvNeXt MLP, whose forward keeps only the
+// pre-activation): applied to the staged registers on their way into LDS, once per element and N tile.
+template <int WN, int WK, int TNn, int TK, bool BUF, bool XG>
 __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
                                                                   const bf16_t* __restrict__ dy, long lddy, int Np,
                                                                   long M, int K, long rows_per_split,
@@ -809,7 +811,14 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
     for (int i = 0; i < DCH; ++i)
       if ((TN_ROWS * CPRD) % NTHR == 0 || tid + NTHR * i < TN_ROWS * CPRD) *reinterpret_cast<bf16x8*>(Ds + d_lds[i]) = rd[i];
 #pragma unroll
-    for (int i = 0; i < XCH; ++i) *reinterpret_cast<bf16x8*>(Xs + (xr + XSTEP * i) * LDX + xc * 8) = rx[i];
+    for (int i = 0; i < XCH; ++i) {
+      bf16x8 v = rx[i];
+      if constexpr (XG) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (bf16_t)gelu_t<bf16_t>((float)v[q]);
+      }
+      *reinterpret_cast<bf16x8*>(Xs + (xr + XSTEP * i) * LDX + xc * 8) = v;
+    }
   };
 
   f32x4 acc[TNn][TK];
@@ -1282,7 +1291,7 @@ int vkas_gemm_nt_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* B
   return VKAS_OK;
 }
 
-template <int WN, int WK, int TNn, int TK>
+template <int WN, int WK, int TNn, int TK, bool XG>
 static void launch_tn(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, long M, int K, float* gw,
                       float* gb, hipStream_t st) {
   constexpr int BNn = WN * TNn * 16, BKc = WK * TK * 16;
@@ -1317,11 +1326,11 @@ static void launch_tn(const void* x, const vkas_conv_geom* g, const void* dy, lo
   const long dy_bytes = ((M - 1) * lddy + Np) * 2;
   static const bool no_buf = getenv("VKAS_TN_NOBUF") != nullptr;
   if (!no_buf && x_bytes < 0xFFFFFFF0L && dy_bytes < 0xFFFFFFF0L)
-    gemm_tn_mfma_kernel<WN, WK, TNn, TK, true><<<grid, WN * WK * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy, Np,
+    gemm_tn_mfma_kernel<WN, WK, TNn, TK, true, XG><<<grid, WN * WK * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy, Np,
                                                                              M, K, rows, gw, gb, (unsigned)x_bytes,
                                                                              (unsigned)dy_bytes);
   else
-    gemm_tn_mfma_kernel<WN, WK, TNn, TK, false><<<grid, WN * WK * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy,
+    gemm_tn_mfma_kernel<WN, WK, TNn, TK, false, XG><<<grid, WN * WK * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy,
                                                                               Np, M, K, rows, gw, gb, 0u, 0u);
 }
 
@@ -1346,14 +1355,14 @@ int vkas_gemm_tn_tile_choice(long M, int Np, int K) {
 }
 
 int vkas_gemm_tn_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
-                           float* gb, hipStream_t st) {
+                           float* gb, int x_gelu, hipStream_t st) {
   const long M = (long)g->B * g->Hout * g->Wout;
   const int K = g->KH * g->KW * g->Cp;
   if (M == 0) return VKAS_OK;
   // row-aligned 3x3 / stride 1 / pad 1 with wide operands: the slab kernel
   const long x_bytes = (((long)g->B * g->Hin * g->Win - 1) * g->ldx + g->Cp) * 2;
   const long dy_bytes = ((M - 1) * lddy + Np) * 2;
-  if (vkas_tn_slab_eligible(g, Np, lddy)) {
+  if (!x_gelu && vkas_tn_slab_eligible(g, Np, lddy)) {
     const bool n112 = vkas_tn_slab_n112(Np);
     const long tiles = vkas_cdiv(Np, n112 ? 112 : 128) * 3 * vkas_cdiv(g->Cp, 128);
     const long chunks = M / 64;
@@ -1378,9 +1387,13 @@ int vkas_gemm_tn_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* d
     return VKAS_OK;
   }
   const int bn = vkas_gemm_tn_tile_choice(M, Np, K);
-  if (bn == 224) launch_tn<2, 4, 7, 4>(x, g, dy, lddy, Np, M, K, gw, gb, st);
-  else if (bn == 192) launch_tn<2, 4, 6, 4>(x, g, dy, lddy, Np, M, K, gw, gb, st);
-  else launch_tn<2, 2, 4, 4>(x, g, dy, lddy, Np, M, K, gw, gb, st);
+  if (x_gelu) {
+    if (bn == 224) launch_tn<2, 4, 7, 4, true>(x, g, dy, lddy, Np, M, K, gw, gb, st);
+    else if (bn == 192) launch_tn<2, 4, 6, 4, true>(x, g, dy, lddy, Np, M, K, gw, gb, st);
+    else launch_tn<2, 2, 4, 4, true>(x, g, dy, lddy, Np, M, K, gw, gb, st);
+  } else if (bn == 224) launch_tn<2, 4, 7, 4, false>(x, g, dy, lddy, Np, M, K, gw, gb, st);
+  else if (bn == 192) launch_tn<2, 4, 6, 4, false>(x, g, dy, lddy, Np, M, K, gw, gb, st);
+  else launch_tn<2, 2, 4, 4, false>(x, g, dy, lddy, Np, M, K, gw, gb, st);
   VKAS_LAUNCH_CHECK("gemm_tn_mfma");
   return VKAS_OK;
 }

@@ -80,7 +80,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gemm_tn_simple_kernel(const T* __restrict__ x, vkas_conv_geom g,
                                                              const T* __restrict__ dy, long lddy, int Np, long M,
                                                              int K, long rows_per_split, float* __restrict__ gw,
-                                                             float* __restrict__ gb) {
+                                                             float* __restrict__ gb, int x_gelu) {
   __shared__ __attribute__((aligned(16))) float Ds[TK][LDT];  // [m][n]
   __shared__ __attribute__((aligned(16))) float Xs[TK][LDT];  // [m][k]
   const int tid = threadIdx.x;
@@ -122,6 +122,10 @@ __global__ __launch_bounds__(256) void gemm_tn_simple_kernel(const T* __restrict
         const RowCoord rc = decode_row(m, M, g);
         const long off = tap_offset(rc, ky, kx, g);
         if (off >= 0) load4(x + off + c, xv);
+        if (x_gelu) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xv[i] = gelu_t<T>(xv[i]);
+        }
       }
     }
     *reinterpret_cast<float4*>(&Ds[mi][q]) = make_float4(dv[0], dv[1], dv[2], dv[3]);
@@ -177,7 +181,7 @@ int vkas_gemm_nt_simple(const void* x, const vkas_conv_geom* g, const void* Bw, 
 }
 
 int vkas_gemm_tn_simple(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
-                        float* gb, int dtype, hipStream_t st) {
+                        float* gb, int x_gelu, int dtype, hipStream_t st) {
   const long M = (long)g->B * g->Hout * g->Wout;
   const int K = g->KH * g->KW * g->Cp;
   if (M == 0) return VKAS_OK;
@@ -192,7 +196,7 @@ int vkas_gemm_tn_simple(const void* x, const vkas_conv_geom* g, const void* dy, 
   splits = vkas_cdiv(M, rows);
   dim3 grid((unsigned)vkas_cdiv(Np, TS), (unsigned)vkas_cdiv(K, TS), (unsigned)splits);
   VKAS_DISPATCH_DTYPE(dtype, "gemm_tn_simple", {
-    gemm_tn_simple_kernel<T><<<grid, 256, 0, st>>>((const T*)x, *g, (const T*)dy, lddy, Np, M, K, rows, gw, gb);
+    gemm_tn_simple_kernel<T><<<grid, 256, 0, st>>>((const T*)x, *g, (const T*)dy, lddy, Np, M, K, rows, gw, gb, x_gelu);
   })
   VKAS_LAUNCH_CHECK("gemm_tn_simple");
   return VKAS_OK;

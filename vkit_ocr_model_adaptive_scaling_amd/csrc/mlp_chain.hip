@@ -1,0 +1,503 @@
+// ConvNeXt MLP as ONE kernel per direction (model/convnext.py:33-35,54-58: Linear(C,4C) -> GELU -> Linear(4C,C) ->
+// layer scale -> stochastic depth -> residual), for C <= 256: the (pixels x 4C) intermediate never round-trips HBM
+// between the two GEMMs.
+//
+//   forward : h = yn W1^T + b1 (stored once, bf16, for backward); g = gelu(h) stays in registers;
+//             z = g W2^T + b2 (stored, C wide); out = x + rowscale[b] * colscale * z.
+//   backward: dg = dz W2; dh = dg * gelu'(h) (stored once for the W1 weight gradient); dyn = dh W1.
+//
+// Structure (both directions are the same chain  GEMM-a (K = C) -> elementwise -> GEMM-b (K = 4C, N = C)):
+//  * a wave owns TM x 16 pixel rows and ALL columns: its input rows live in registers as MFMA B fragments for the whole
+//    kernel (read from HBM once, straight into the fragment layout), the C-wide output tile in fp32 accumulators.
+//  * the 4C hidden units are walked in chunks of 32.  Per chunk GEMM-a produces two 16x16 D tiles per row group; with
+//    v_mfma_f32_16x16x32 (operands swapped, D^T = W X^T) a lane then holds hidden units {4g..4g+3} and {16+4g..16+4g+3}
+//    of one pixel - exactly one K = 32 B fragment of GEMM-b if the weight side uses the same k permutation.  So the
+//    activation goes from the first matrix product into the second without touching LDS; the permutation is baked into
+//    the packed weight image.
+//  * weights: per chunk one pre-swizzled LDS image (GEMM-a tile [32][K] + GEMM-b tile [C][32]) that the pack kernel
+//    lays out in global memory byte for byte as it must sit in LDS, so staging is a linear LDS-DMA copy
+//    (buffer_load_dwordx4 ... lds), double buffered, one barrier per chunk.  All workgroups stream the same
+//    147 KB - 1 MB of weights from L2.
+//  * 256 threads, two workgroups per CU: one workgroup's epilogue / prologue overlaps the other's main loop.
+#include "vkas_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+constexpr int MODE_FWD = 0, MODE_BWD = 1;
+
+// Timing-only ablation switches for profiles/bench_chain.py (never set in the shipped build; results are wrong when set):
+// 1 no h / dh stores, 2 no epilogue traffic, 4 no GELU arithmetic, 8 no h loads (backward).
+#ifndef CHAIN_ABL
+#define CHAIN_ABL 0
+#endif
+constexpr int ABL = CHAIN_ABL;
+
+__host__ __device__ constexpr int chain_ka(int KS) { return ((KS + 1) / 2) * 64; }          // K extent of the stored GEMM-a tile
+// per chunk: GEMM-a tile + GEMM-b tile + one 1-KB piece whose first 128 bytes hold the chunk's 32 GEMM-a biases (fp32)
+__host__ __device__ constexpr int chain_img_elems(int KS) { return 32 * chain_ka(KS) + KS * 32 * 32 + 512; }
+
+// ---- packed weight image -------------------------------------------------------------------------------------------
+// chunk j (hidden units 32 j .. 32 j + 31):
+//   A region: sub-tiles s = 0 .. KA/64 - 1 of [32 hidden][64 k], 16-byte chunk c of row h stored at position c ^ (h & 7);
+//   B region: [CB = 32 KS output rows][32 k slots] viewed as [CB / 2][64]: row n, slot group g -> row R = n >> 1, chunk
+//             ((n & 1) * 4 + g) ^ (R & 7); k slot q of group g is hidden unit (q >> 2) * 16 + 4 g + (q & 3);
+//   bias piece: 32 fp32 (b1 of the chunk's hidden units; zeros in the backward image), rest of the 1-KB piece unused.
+// mode 0 (forward): A = W1 rows, B = W2; mode 1 (backward): A[h][c] = W2[c][h], B[c][h] = W1[h][c].
+template <typename T>
+__global__ void mlp_chain_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+                                      const float* __restrict__ b1, int C, int HID, int KS, int mode, T* __restrict__ img) {
+  const int KA = chain_ka(KS);
+  const int pieces = chain_img_elems(KS) / 8;  // 16-byte pieces per chunk image
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nchunks = HID / 32;
+  if (idx >= (long)nchunks * pieces) return;
+  const int j = (int)(idx / pieces);
+  int p = (int)(idx - (long)j * pieces);
+  float v[8];
+  const int a_pieces = 32 * KA / 8;
+  const int b_pieces = KS * 32 * 32 / 8;
+  if (p >= a_pieces + b_pieces) {  // bias piece: fp32 values, 4 per 16-byte piece
+    const int q = p - a_pieces - b_pieces;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < 8 && mode == 0 && b1) bv = *reinterpret_cast<const float4*>(b1 + j * 32 + q * 4);
+    *reinterpret_cast<float4*>(img + idx * 8) = bv;
+    return;
+  }
+  if (p < a_pieces) {
+    const int s = p / 256, rem = p - s * 256;
+    const int h = rem >> 3, cpos = rem & 7;
+    const int c = cpos ^ (h & 7);
+    const int k0 = s * 64 + c * 8;
+    const int hid = j * 32 + h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = k0 + i;
+      v[i] = k < C ? (mode == 0 ? w1[(long)hid * C + k] : w2[(long)k * HID + hid]) : 0.f;
+    }
+  } else {
+    p -= a_pieces;
+    const int R = p >> 3, cpos = p & 7;
+    const int c = cpos ^ (R & 7);
+    const int n = R * 2 + (c >> 2), g = c & 3;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int hid = j * 32 + (q >> 2) * 16 + g * 4 + (q & 3);
+      v[q] = n < C ? (mode == 0 ? w2[(long)n * HID + hid] : w1[(long)hid * C + n]) : 0.f;
+    }
+  }
+  store8(img + idx * 8, v);
+}
+
+struct ChainArgs {
+  const void* a;        // [M][lda] input rows: yn (fwd) / dz (bwd)
+  long lda;
+  const void* img;      // packed weight chunks
+  void* mid_out;        // fwd: h, bwd: dh   [M][ldm]
+  long ldm;
+  const void* mid_in;   // bwd: h            [M][ldmi]
+  long ldmi;
+  const float* bias_b;  // fwd: b2 (C)
+  const void* res;      // fwd: x (residual) [M][ldres]
+  long ldres;
+  const float* colscale;  // fwd: block_scale (C)
+  const float* rowscale;  // fwd: per-image keep mask / keep probability, or null
+  int rows_per_image;
+  void* z;              // fwd: pre-scale MLP output [M][ldz]
+  long ldz;
+  void* out;            // fwd: layer output, bwd: dyn [M][ldo]
+  long ldo;
+  long M;
+  int C, HID;
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { typedef bf16x8 v8; typedef bf16x4 v4; };
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <typename T, int KS, int TM, int MODE, int MINB>
+__global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
+  typedef typename Frag<T>::v8 v8;
+  typedef typename Frag<T>::v4 v4;
+  constexpr int NT2 = 2 * KS;                // 16-wide output column tiles of GEMM-b
+  constexpr int KA = chain_ka(KS);
+  constexpr int IMG = chain_img_elems(KS);   // elements per chunk image
+  constexpr int NI = IMG * 2 / 1024;         // 1-KB DMA instructions per chunk image
+  constexpr int ROWS = TM * 16;              // pixel rows per wave
+  constexpr int STG = ROWS * 64;             // per-wave staging of one chunk PAIR of the 4C-wide tensor: ROWS x 128 B
+  constexpr int NF = ROWS / 8;               // 1-KB pieces (8 rows x 128 B) of that staging buffer
+  constexpr int PE = KS * 32 + 8;            // epilogue staging row pitch (elements): odd multiple of 16 B
+  constexpr int LDS_MAIN = 2 * IMG + 4 * STG, LDS_EPI = 4 * ROWS * PE;
+  constexpr int LDS_ELEMS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+  static_assert((IMG * 2) % 1024 == 0, "chunk image must be whole 1-KB DMA pieces");
+  __shared__ __attribute__((aligned(1024))) T lds[LDS_ELEMS];
+  typedef __attribute__((address_space(3))) T lds_T;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, g = lane >> 4;
+  const int C = p.C;
+  const long row0 = ((long)blockIdx.x * 4 + wave) * ROWS;
+  const int nchunks = p.HID / 32;
+  const bool full_rows = row0 + ROWS <= p.M;  // wave-uniform
+  const int n_img = (NI - wave + 3) / 4;      // image DMA instructions this wave issues per chunk (q*4 + wave < NI)
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.img, (short)0, (int)((long)nchunks * IMG * 2), 0x00020000);
+  auto issue_chunk = [&](int j, int buf) {
+#pragma unroll
+    for (int q = 0; q < (NI + 3) / 4; ++q) {
+      const int inst = q * 4 + wave;
+      if (inst >= NI) break;  // wave-uniform
+      const unsigned voff = (unsigned)j * (unsigned)(IMG * 2) + (unsigned)inst * 1024u + (unsigned)lane * 16u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_ptr)((lds_T*)lds + buf * IMG + inst * 512), 16, voff, 0, 0, 0);
+    }
+  };
+  issue_chunk(0, 0);
+
+  // Pair staging buffer of this wave (the 4C-wide tensor moves in 128-byte row pieces = two chunks): row r, logical
+  // 16-byte piece c sits at position c ^ ((r >> 1) & 7) (the 16 rows x 2 halves a b64 access touches hit 64 distinct
+  // banks); a 1-KB DMA / flush instruction covers 8 rows, lane = (row & 7) * 8 + position.
+  T* stg = lds + 2 * IMG + wave * STG;
+  auto stg_off = [&](int r, int e) { return r * 64 + ((((e >> 3) ^ (r >> 1)) & 7) << 3) + (e & 7); };
+  const int f_r = lane >> 3, f_pp = lane & 7;  // flush / DMA role: row f_r of a piece, position f_pp
+  // backward: saved pre-activations of chunk pair P -> staging buffer (LDS-DMA, whole 128-byte row pieces)
+  __amdgpu_buffer_rsrc_t rs_h;
+  if constexpr (MODE == MODE_BWD)
+    rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)p.mid_in, (short)0, (int)(((p.M - 1) * p.ldmi + p.HID) * 2), 0x00020000);
+  auto issue_h = [&](int P) {
+#pragma unroll
+    for (int it = 0; it < NF; ++it) {
+      const int r = it * 8 + f_r;
+      const int c = (f_pp ^ (r >> 1)) & 7;
+      const long m = row0 + r;
+      const bool ok = m < p.M && P * 64 + c * 8 < p.HID && !(ABL & 8);
+      const unsigned voff = ok ? (unsigned)((m * p.ldmi + P * 64 + c * 8) * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (lds_void_ptr)((lds_T*)stg + it * 512), 16, voff, 0, 0, 0);
+    }
+  };
+  // staged pair -> global (h forward, dh backward): 8 rows x 128 B per instruction, whole cache lines
+  auto flush_pair = [&](int P, int width) {
+    T* G = reinterpret_cast<T*>(p.mid_out);
+#pragma unroll 2
+    for (int it = 0; it < NF; ++it) {
+      const int r = it * 8 + f_r;
+      const int c = (f_pp ^ (r >> 1)) & 7;
+      const long m = row0 + r;
+      const v8 v = *reinterpret_cast<const v8*>(stg + r * 64 + f_pp * 8);
+      if (m < p.M && c * 8 < width && !(ABL & 1)) *reinterpret_cast<v8*>(G + m * p.ldm + P * 64 + c * 8) = v;
+    }
+  };
+
+  // input rows -> B fragments (row fr of group i, k = ks*32 + g*8 .. +7), resident for the whole kernel
+  v8 xf[TM][KS];
+  const T* A = reinterpret_cast<const T*>(p.a);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const long m = row0 + i * 16 + fr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = ks * 32 + g * 8;
+      v8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (m < p.M && k < C) v = *reinterpret_cast<const v8*>(A + m * p.lda + k);
+      xf[i][ks] = v;
+    }
+  }
+  f32x4 acc[TM][NT2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (MODE == MODE_BWD) issue_h(0);
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  for (int j = 0; j < nchunks; ++j) {
+    const int buf = j & 1, par = j & 1;
+    const bool more = j + 1 < nchunks;
+    if (more) issue_chunk(j + 1, buf ^ 1);
+    const T* Wa = lds + buf * IMG;
+    const T* Wb = Wa + 32 * KA;
+    const float* Ba = reinterpret_cast<const float*>(Wb + KS * 1024);
+    // ---- GEMM-a: d[i][t] (lane: pixel fr of group i, hidden units t*16 + 4g .. +3 of this chunk)
+    f32x4 d[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      d[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      d[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      v8 wa[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int h = t * 16 + fr;
+        const int c = (ks & 1) * 4 + g;
+        wa[t] = *reinterpret_cast<const v8*>(Wa + (ks >> 1) * 2048 + h * 64 + ((c ^ (h & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        d[i][0] = mfma16(wa[0], xf[i][ks], d[i][0]);
+        d[i][1] = mfma16(wa[1], xf[i][ks], d[i][1]);
+      }
+    }
+    // ---- elementwise middle: the GEMM-b operand of this chunk, built in registers; the 4C-wide values go through the
+    //      pair staging buffer (this lane: hidden units e0 .. e0+3 and e0+16 .. e0+19 of the pair's 64)
+    v8 gf[TM];
+    const int e0 = par * 32 + g * 4;
+    if constexpr (MODE == MODE_FWD) {
+      const float4 b0 = *reinterpret_cast<const float4*>(Ba + g * 4);       // bias from the LDS image: a VMEM load here
+      const float4 b1 = *reinterpret_cast<const float4*>(Ba + g * 4 + 16);  // would make the compiler wait for the stores
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int r = i * 16 + fr;
+        float v[8] = {d[i][0][0] + b0.x, d[i][0][1] + b0.y, d[i][0][2] + b0.z, d[i][0][3] + b0.w,
+                      d[i][1][0] + b1.x, d[i][1][1] + b1.y, d[i][1][2] + b1.z, d[i][1][3] + b1.w};
+        v4 h0, h1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          h0[q] = (T)v[q];
+          h1[q] = (T)v[4 + q];
+        }
+        *reinterpret_cast<v4*>(stg + stg_off(r, e0)) = h0;
+        *reinterpret_cast<v4*>(stg + stg_off(r, e0 + 16)) = h1;
+        // GELU of the stored (rounded) pre-activation: what backward will differentiate
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          gf[i][q] = (ABL & 4) ? h0[q] : (T)gelu_t<T>((float)h0[q]);
+          gf[i][4 + q] = (ABL & 4) ? h1[q] : (T)gelu_t<T>((float)h1[q]);
+        }
+      }
+    } else {
+      if (par == 0 && j > 0) {
+        // the pair's h (DMA issued in the previous chunk, before its GEMM-b) must have landed; only this chunk's image
+        // DMA is younger
+        if (!full_rows || !more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (n_img == (NI + 3) / 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NI + 3) / 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NI + 3) / 4 - 1) : "memory");
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int r = i * 16 + fr;
+        const v4 h0 = *reinterpret_cast<const v4*>(stg + stg_off(r, e0));
+        const v4 h1 = *reinterpret_cast<const v4*>(stg + stg_off(r, e0 + 16));
+        v4 o0, o1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          o0[q] = (T)(d[i][0][q] * ((ABL & 4) ? (float)h0[q] : dgelu_t<T>((float)h0[q])));
+          o1[q] = (T)(d[i][1][q] * ((ABL & 4) ? (float)h1[q] : dgelu_t<T>((float)h1[q])));
+        }
+        *reinterpret_cast<v4*>(stg + stg_off(r, e0)) = o0;  // in place: dh over h
+        *reinterpret_cast<v4*>(stg + stg_off(r, e0 + 16)) = o1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          gf[i][q] = o0[q];
+          gf[i][4 + q] = o1[q];
+        }
+      }
+    }
+    const bool flush_now = par == 1 || !more;
+    if (flush_now) {
+      flush_pair(j >> 1, par == 1 ? 64 : 32);
+      if constexpr (MODE == MODE_BWD) {
+        if (more) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the flush has read the buffer
+          issue_h((j + 1) >> 1);
+        }
+      }
+    }
+    // ---- GEMM-b: acc[i][n] += Wb[n rows][32 k slots] . gf[i]
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) {
+      const int row = n * 16 + fr;
+      const int R = row >> 1, c = (row & 1) * 4 + g;
+      const v8 wb = *reinterpret_cast<const v8*>(Wb + R * 64 + ((c ^ (R & 7)) << 3));
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i][n] = mfma16(wb, gf[i], acc[i][n]);
+    }
+    // The next chunk's image (issued at the top of this iteration) must have landed.  What this chunk issued after it
+    // - the flush stores and, backward, the next pair's h DMA - is younger and stays in flight: a full drain (which
+    // __syncthreads() implies) would put the HBM store latency on the critical path of every chunk.  A wave with rows
+    // beyond M may have skipped stores, so its count of younger operations is unknown: it drains.
+    if (more) {
+      if (!full_rows || !flush_now || ABL != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if constexpr (MODE == MODE_FWD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NF) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NF) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  // ---- epilogue.  The accumulators (lane: pixel fr of group i, channels n*16 + 4g .. +3) go through a per-wave LDS tile
+  // (the weight images are dead) so that every global access is a 16-byte piece of a whole row: lane = piece of row
+  // (it * RPI + lane / PCS), PCS = C / 8 pieces per row, RPI rows per instruction.
+  if ((ABL & 2) && acc[0][0][0] != 1.2345f) return;
+  T* ep = lds + wave * (ROWS * PE);
+#pragma unroll
+  for (int n = 0; n < NT2; ++n) {
+    const int col = n * 16 + g * 4;
+    float4 b2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (MODE == MODE_FWD) {
+      if (col < C) b2 = *reinterpret_cast<const float4*>(p.bias_b + col);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      v4 zq;
+      zq[0] = (T)(acc[i][n][0] + b2.x);
+      zq[1] = (T)(acc[i][n][1] + b2.y);
+      zq[2] = (T)(acc[i][n][2] + b2.z);
+      zq[3] = (T)(acc[i][n][3] + b2.w);
+      *reinterpret_cast<v4*>(ep + (i * 16 + fr) * PE + col) = zq;
+    }
+  }
+  const int PCS = C >> 3;
+  const int RPI = 64 / PCS;
+  const int piece = lane % PCS, rsub = lane / PCS;
+  float cs[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) cs[q] = 0.f;
+  if constexpr (MODE == MODE_FWD) load8(p.colscale + piece * 8, cs);
+  // image of this lane's current row (rowscale index), advanced without divisions
+  long m = row0 + rsub;
+  int img = 0, rim = 0;
+  if constexpr (MODE == MODE_FWD) {
+    img = (int)(m / p.rows_per_image);
+    rim = (int)(m - (long)img * p.rows_per_image);
+  }
+  if (rsub < RPI) {
+    for (int r = rsub; r < ROWS; r += RPI) {
+      if (m < p.M) {
+        const v8 zq = *reinterpret_cast<const v8*>(ep + r * PE + piece * 8);
+        if constexpr (MODE == MODE_FWD) {
+          // z is stored in the activation type and the residual uses the rounded value (as the two-kernel path does)
+          *reinterpret_cast<v8*>(reinterpret_cast<T*>(p.z) + m * p.ldz + piece * 8) = zq;
+          const float rs = p.rowscale ? p.rowscale[img] : 1.0f;
+          float xr[8];
+          load8(reinterpret_cast<const T*>(p.res) + m * p.ldres + piece * 8, xr);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) xr[q] += rs * cs[q] * (float)zq[q];
+          store8(reinterpret_cast<T*>(p.out) + m * p.ldo + piece * 8, xr);
+        } else {
+          *reinterpret_cast<v8*>(reinterpret_cast<T*>(p.out) + m * p.ldo + piece * 8) = zq;
+        }
+      }
+      m += RPI;
+      if constexpr (MODE == MODE_FWD) {
+        rim += RPI;
+        while (rim >= p.rows_per_image) {
+          rim -= p.rows_per_image;
+          ++img;
+        }
+      }
+    }
+  }
+}
+
+// KS (32-wide K steps covering C) and rows per wave for a channel count, 0 when the chain kernels do not cover it
+static int chain_ks(int C) {
+  if (C <= 0 || C % 8 != 0 || C > 256) return 0;
+  const int ks = (C + 31) / 32;
+  return ks <= 4 ? ks : (ks <= 6 ? 6 : 8);
+}
+
+template <typename T, int MODE>
+static int launch_chain(const ChainArgs& a, hipStream_t st) {
+  const int ks = chain_ks(a.C);
+#define VKAS_CHAIN(KSV, TMV, MINB)                                                                \
+  {                                                                                               \
+    const long rows_per_block = 4L * TMV * 16;                                                    \
+    const unsigned grid = (unsigned)vkas_cdiv(a.M, rows_per_block);                               \
+    mlp_chain_kernel<T, KSV, TMV, MODE, MINB><<<grid, 256, 0, st>>>(a);                           \
+  }
+  switch (ks) {
+    case 1: VKAS_CHAIN(1, 4, 2) break;
+    case 2: VKAS_CHAIN(2, 4, 2) break;
+    case 3: VKAS_CHAIN(3, 4, 2) break;
+    case 4: VKAS_CHAIN(4, 2, 2) break;
+    case 6: VKAS_CHAIN(6, 2, 2) break;
+    case 8: VKAS_CHAIN(8, 2, 1) break;
+    default:
+      vkas_set_error("vkas_mlp_chain: C=%d is not covered (multiple of 8, <= 256)", a.C);
+      return VKAS_E_ARG;
+  }
+#undef VKAS_CHAIN
+  return VKAS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t vkas_mlp_chain_image_elems(int C) {
+  const int ks = chain_ks(C);
+  return ks ? (size_t)(4 * C / 32) * (size_t)chain_img_elems(ks) : 0;
+}
+
+extern "C" int vkas_mlp_chain_pack(const float* w1, const float* w2, const float* b1, int C, int mode, void* img, int dtype,
+                                   void* stream) {
+  VKAS_CHECK(w1 && w2 && img && vkas_aligned16(img) && (mode != 0 || (b1 && vkas_aligned16(b1))),
+             "vkas_mlp_chain_pack: null / misaligned pointer");
+  const int ks = chain_ks(C);
+  VKAS_CHECK(ks > 0, "vkas_mlp_chain_pack: C=%d is not covered (multiple of 8, <= 256)", C);
+  VKAS_CHECK(mode == 0 || mode == 1, "vkas_mlp_chain_pack: mode must be 0 (forward) or 1 (backward)");
+  VKAS_CHECK(dtype == VKAS_BF16, "vkas_mlp_chain_pack: bf16 only");
+  const long pieces = (long)(4 * C / 32) * (chain_img_elems(ks) / 8);
+  mlp_chain_pack_kernel<bf16_t><<<(unsigned)vkas_cdiv(pieces, 256), 256, 0, vkas_stream(stream)>>>(w1, w2, b1, C, 4 * C, ks,
+                                                                                                   mode, (bf16_t*)img);
+  VKAS_LAUNCH_CHECK("mlp_chain_pack");
+  return VKAS_OK;
+}
+
+static int chain_check_act(const char* who, const void* p, long ld, int width) {
+  VKAS_CHECK(p && vkas_aligned16(p) && ld >= width && ld % 8 == 0, "%s: bad activation operand (ld=%ld, width=%d)", who, ld, width);
+  return VKAS_OK;
+}
+
+extern "C" int vkas_mlp_chain_fwd(const void* yn, long ldyn, const void* img, const float* b2, const void* x, long ldx, const float* colscale, const float* rowscale, int rows_per_image, void* h, long ldh,
+                                  void* z, long ldz, void* out, long ldo, long M, int C, int dtype, void* stream) {
+  const char* who = "vkas_mlp_chain_fwd";
+  VKAS_CHECK(dtype == VKAS_BF16, "%s: bf16 only", who);
+  VKAS_CHECK(chain_ks(C) > 0, "%s: C=%d is not covered (multiple of 8, <= 256)", who, C);
+  VKAS_CHECK(img && b2 && colscale && vkas_aligned16(img) && vkas_aligned16(b2) && vkas_aligned16(colscale),
+             "%s: null / misaligned parameter", who);
+  VKAS_CHECK(M >= 0 && rows_per_image > 0, "%s: bad sizes", who);
+  int rc;
+  if ((rc = chain_check_act(who, yn, ldyn, C)) || (rc = chain_check_act(who, x, ldx, C)) || (rc = chain_check_act(who, h, ldh, 4 * C)) ||
+      (rc = chain_check_act(who, z, ldz, C)) || (rc = chain_check_act(who, out, ldo, C)))
+    return rc;
+  if (M == 0) return VKAS_OK;
+  ChainArgs a = {};
+  a.a = yn; a.lda = ldyn; a.img = img; a.mid_out = h; a.ldm = ldh; a.bias_b = b2; a.res = x; a.ldres = ldx;
+  a.colscale = colscale; a.rowscale = rowscale; a.rows_per_image = rows_per_image; a.z = z; a.ldz = ldz; a.out = out; a.ldo = ldo;
+  a.M = M; a.C = C; a.HID = 4 * C;
+  rc = launch_chain<bf16_t, MODE_FWD>(a, vkas_stream(stream));
+  if (rc) return rc;
+  VKAS_LAUNCH_CHECK("mlp_chain_fwd");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_mlp_chain_bwd(const void* dz, long lddz, const void* img_t, const void* h, long ldh, void* dh, long lddh,
+                                  void* dyn, long lddyn, long M, int C, int dtype, void* stream) {
+  const char* who = "vkas_mlp_chain_bwd";
+  VKAS_CHECK(dtype == VKAS_BF16, "%s: bf16 only", who);
+  VKAS_CHECK(chain_ks(C) > 0, "%s: C=%d is not covered (multiple of 8, <= 256)", who, C);
+  VKAS_CHECK(img_t && vkas_aligned16(img_t) && M >= 0, "%s: bad arguments", who);
+  int rc;
+  if ((rc = chain_check_act(who, dz, lddz, C)) || (rc = chain_check_act(who, h, ldh, 4 * C)) || (rc = chain_check_act(who, dh, lddh, 4 * C)) ||
+      (rc = chain_check_act(who, dyn, lddyn, C)))
+    return rc;
+  if (M == 0) return VKAS_OK;
+  ChainArgs a = {};
+  a.a = dz; a.lda = lddz; a.img = img_t; a.mid_out = dh; a.ldm = lddh; a.mid_in = h; a.ldmi = ldh; a.out = dyn; a.ldo = lddyn;
+  a.M = M; a.C = C; a.HID = 4 * C;
+  rc = launch_chain<bf16_t, MODE_BWD>(a, vkas_stream(stream));
+  if (rc) return rc;
+  VKAS_LAUNCH_CHECK("mlp_chain_bwd");
+  return VKAS_OK;
+}

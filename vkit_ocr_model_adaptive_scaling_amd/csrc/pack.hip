@@ -4,19 +4,24 @@
 
 namespace {
 
+// n_off / Nt: the weight fills output channels [n_off, n_off + Np) of an operand with Nt output channels in total (several
+// convolutions that share their input packed side by side: the heads of a pass); n_off = 0, Nt = Np is the plain case.
 template <typename T>
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int N, int C, int KH, int KW,
-                                        int Np, int Cp, int mode, long total) {
+                                        int Np, int Cp, int mode, long total, int n_off, int Nt) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int n, c, ky, kx;
     long r = i;
+    long o = i;
     if (mode == 0) {  // [n][ky][kx][c]
       c = (int)(r % Cp); r /= Cp;
       kx = (int)(r % KW); r /= KW;
       ky = (int)(r % KH); r /= KH;
       n = (int)r;
+      o = i + (long)n_off * KH * KW * Cp;
     } else if (mode == 1) {  // [c][ky'][kx'][n], taps rotated by 180 degrees
       n = (int)(r % Np); r /= Np;
+      o = r * Nt + n_off + n;
       kx = KW - 1 - (int)(r % KW); r /= KW;
       ky = KH - 1 - (int)(r % KH); r /= KH;
       c = (int)r;
@@ -28,7 +33,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restri
     }
     float v = 0.f;
     if (n < N && c < C) v = w[(((long)n * C + c) * KH + ky) * KW + kx];
-    out[i] = from_f32<T>(v);
+    out[o] = from_f32<T>(v);
   }
 }
 
@@ -158,9 +163,26 @@ extern "C" int vkas_pack_conv_weight(const float* w, void* out, int N, int C, in
   const long total = (long)Np * KH * KW * Cp;
   VKAS_DISPATCH_DTYPE(dtype, "vkas_pack_conv_weight", {
     pack_conv_weight_kernel<T><<<grid1d(total), 256, 0, vkas_stream(stream)>>>(w, (T*)out, N, C, KH, KW, Np, Cp, mode,
-                                                                              total);
+                                                                              total, 0, Np);
   })
   VKAS_LAUNCH_CHECK("pack_conv_weight");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_pack_conv_weight_slice(const float* w, void* out, int N, int C, int KH, int KW, int Np, int Cp, int mode,
+                                           int n_off, int Nt, int dtype, void* stream) {
+  VKAS_CHECK(w && out, "vkas_pack_conv_weight_slice: null pointer");
+  VKAS_CHECK(N > 0 && C > 0 && KH > 0 && KW > 0 && Np >= N && Cp >= C && Np % 8 == 0 && Cp % 8 == 0,
+             "vkas_pack_conv_weight_slice: bad dims N=%d C=%d Np=%d Cp=%d", N, C, Np, Cp);
+  VKAS_CHECK(mode == 0 || mode == 1, "vkas_pack_conv_weight_slice: mode must be 0 (forward) or 1 (dgrad)");
+  VKAS_CHECK(n_off >= 0 && n_off % 8 == 0 && Nt % 8 == 0 && n_off + Np <= Nt, "vkas_pack_conv_weight_slice: bad slice %d + %d of %d",
+             n_off, Np, Nt);
+  const long total = (long)Np * KH * KW * Cp;
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_pack_conv_weight_slice", {
+    pack_conv_weight_kernel<T><<<grid1d(total), 256, 0, vkas_stream(stream)>>>(w, (T*)out, N, C, KH, KW, Np, Cp, mode,
+                                                                              total, n_off, Nt);
+  })
+  VKAS_LAUNCH_CHECK("pack_conv_weight_slice");
   return VKAS_OK;
 }
 
@@ -186,6 +208,40 @@ extern "C" int vkas_pack_dw_weight(const float* w, float* out, int C, int Cp, in
   VKAS_CHECK(w && out && C > 0 && Cp >= C && Cp % 8 == 0, "vkas_pack_dw_weight: bad arguments");
   pack_dw_weight_kernel<<<(unsigned)vkas_cdiv(49L * Cp, 256), 256, 0, vkas_stream(stream)>>>(w, out, C, Cp, flip);
   VKAS_LAUNCH_CHECK("pack_dw_weight");
+  return VKAS_OK;
+}
+
+// dst[k][i] += src[k][i] for up to 16 short fp32 vectors in one launch (blockIdx.y = vector): the per-parameter
+// gradient vectors of a layer (biases, LayerNorm affine, layer scale) added onto their flat-buffer views.
+struct AccumMany {
+  const float* src[16];
+  float* dst[16];
+  int n[16];
+};
+__global__ void accumulate_many_kernel(AccumMany a) {
+  const int k = blockIdx.y;
+  const float* s = a.src[k];
+  float* d = a.dst[k];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n[k]; i += gridDim.x * blockDim.x) d[i] += s[i];
+}
+
+extern "C" int vkas_accumulate_many(int count, const float* const* src, float* const* dst, const int* n, void* stream) {
+  VKAS_CHECK(count >= 0 && count <= 16 && (count == 0 || (src && dst && n)), "vkas_accumulate_many: bad arguments (count=%d)", count);
+  if (count == 0) return VKAS_OK;
+  AccumMany a;
+  int nmax = 0;
+  for (int k = 0; k < count; ++k) {
+    VKAS_CHECK(src[k] && dst[k] && n[k] >= 0, "vkas_accumulate_many: bad vector %d", k);
+    a.src[k] = src[k];
+    a.dst[k] = dst[k];
+    a.n[k] = n[k];
+    nmax = n[k] > nmax ? n[k] : nmax;
+  }
+  if (nmax == 0) return VKAS_OK;
+  long bx = vkas_cdiv(nmax, 256);
+  if (bx > 64) bx = 64;
+  accumulate_many_kernel<<<dim3((unsigned)bx, (unsigned)count), 256, 0, vkas_stream(stream)>>>(a);
+  VKAS_LAUNCH_CHECK("accumulate_many");
   return VKAS_OK;
 }
 

@@ -99,22 +99,23 @@ class AdaptiveScaling(nn.Module):
         plain = [h[0] if isinstance(h, nn.Sequential) else h for h in heads]
         up = plain[0].upsample_act(neck_feature)
         convs, norms, projs = zip(*[h.conv_norm_proj() for h in plain])
+        if ops.HeadsFused.eligible(up, [c.out_channels for c in convs], [hp.out_channels for hp in plain]):
+            # LayerNorm + GELU + projection run in the conv's epilogue: the per-head activations never reach HBM; the
+            # heads' weights are packed side by side by the pack kernel (no torch.cat of parameters on the hot path)
+            fused = []
+            for cv, nm, proj in zip(convs, norms, projs):
+                fused.extend([cv.weight, cv.bias, nm.weight, nm.bias, proj.weight, proj.bias])
+            outs = []
+            for h, hp, y in zip(heads, plain, ops.HeadsFused.apply(up, *fused)):
+                y = ops.ToNchw.apply(y, hp.out_channels)
+                outs.append(h[1](y) if isinstance(h, nn.Sequential) else y)
+            return tuple(outs)
         w_parts, b_parts = [], []
         for c in convs:
             pad = ops.rup8(c.out_channels) - c.out_channels
             w_parts.append(F.pad(c.weight, (0, 0, 0, 0, 0, 0, 0, pad)) if pad else c.weight)
             b_parts.append(F.pad(c.bias, (0, pad)) if pad else c.bias)
         w_cat, b_cat = torch.cat(w_parts, 0), torch.cat(b_parts, 0)
-        if ops.HeadsFused.eligible(up, [c.out_channels for c in convs], [hp.out_channels for hp in plain]):
-            # LayerNorm + GELU + projection run in the conv's epilogue: the per-head activations never reach HBM
-            fused = []
-            for nm, proj in zip(norms, projs):
-                fused.extend([nm.weight, nm.bias, proj.weight, proj.bias])
-            outs = []
-            for h, hp, y in zip(heads, plain, ops.HeadsFused.apply(up, w_cat, b_cat, *fused)):
-                y = ops.ToNchw.apply(y, hp.out_channels)
-                outs.append(h[1](y) if isinstance(h, nn.Sequential) else y)
-            return tuple(outs)
         z = ops.Conv.apply(up, w_cat, b_cat, 1, 1)
         affine = []
         for nm in norms:

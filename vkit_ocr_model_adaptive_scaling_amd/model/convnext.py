@@ -136,9 +136,25 @@ class ConvNext(nn.Module):
     def create_large(cls, stem_use_pconv2x2: bool = False):
         return ConvNext(3, ((192, 3), (384, 3), (768, 27), (1536, 3)), stem_use_pconv2x2)
 
+    def draw_stochastic_depth_masks(self, batch: int, device) -> Optional[List[Optional[torch.Tensor]]]:
+        """convnext.py:41-53 for every block layer at once: per-sample Bernoulli(keep) / keep in training mode (one
+        random draw for the whole backbone instead of one per layer), None in eval mode / for layers that never drop."""
+        layers = [layer for block in self.blocks for layer in block.layers]
+        if not self.training or all(layer.prob_bypass == 0.0 for layer in layers):
+            return None
+        keep = getattr(self, '_keep_probs', None)
+        if keep is None or keep.device != device or keep.numel() != len(layers):
+            keep = torch.tensor([1.0 - layer.prob_bypass for layer in layers], dtype=torch.float32, device=device)
+            self._keep_probs = keep
+        k = keep[:, None]
+        m = (torch.rand((len(layers), batch), dtype=torch.float32, device=device) < k).to(torch.float32) / k.clamp_min(1e-12)
+        return [None if layer.prob_bypass == 0.0 else m[i] for i, layer in enumerate(layers)]
+
     def forward_act(self, x: torch.Tensor, masks: Optional[Sequence[Optional[torch.Tensor]]] = None):
         """x: (B, 3, H, W) raw pixels (fp32 NCHW) -> list of NHWC activations at /4, /8, /16, /32.
         ``masks``: optional per-layer stochastic-depth keep masks (one (B,) tensor or None per block layer)."""
+        if masks is None:
+            masks = self.draw_stochastic_depth_masks(x.shape[0], x.device)
         pconv, norm = self.stem[0], self.stem[2]
         k = pconv.kernel_size[0]
         a = ops.ImageToAct.apply(x, self.compute_dtype)

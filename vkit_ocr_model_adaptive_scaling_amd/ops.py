@@ -8,6 +8,7 @@ needs with the pack kernels.  Every op launches on torch's current HIP stream an
 torch's caching allocator; nothing here falls back to torch math or to the CPU.
 """
 import ctypes
+import os
 import weakref
 from typing import Optional, Sequence, Tuple
 
@@ -128,6 +129,42 @@ def pack_conv_weight(w: torch.Tensor, Np: int, Cp: int, mode: int, dtype: torch.
     return _cached_pack(w, ('conv', Np, Cp, mode, dtype), build)
 
 
+def _cached_pack_pair(a: torch.Tensor, b: torch.Tensor, key, build):
+    """_cached_pack for an operand derived from two parameters (the fused MLP's weight image)."""
+    if not (a.is_leaf and a.requires_grad and b.is_leaf and b.requires_grad):
+        return build()
+    k = (id(a), id(b), key)
+    ent = _PACK_CACHE.get(k)
+    stamp = (a._version, b._version, _PACK_EPOCH[0], a.data_ptr(), b.data_ptr())
+    if ent is not None and ent[0] == stamp and ent[1]() is a and ent[3]() is b:
+        return ent[2]
+    out = build()
+    _PACK_CACHE[k] = (stamp, weakref.ref(a), out, weakref.ref(b))
+    return out
+
+
+_NO_CHAIN = os.environ.get('VKAS_NO_MLP_CHAIN') is not None  # A/B switch: force the two-GEMM layer path
+
+
+def mlp_chain_eligible(x: torch.Tensor, C: int) -> bool:
+    """The fused ConvNeXt MLP kernels (csrc/mlp_chain.hip) cover bf16 activations with C % 8 == 0, C <= 256."""
+    return (not _NO_CHAIN and x.dtype == torch.bfloat16 and x.shape[3] == C
+            and lib.vkas_mlp_chain_image_elems(C) > 0)
+
+
+def pack_mlp_chain(w1: torch.Tensor, w2: torch.Tensor, b1: Optional[torch.Tensor], C: int, mode: int,
+                   dtype: torch.dtype) -> torch.Tensor:
+    """Packed, pre-swizzled weight image of the fused MLP (mode 0 forward incl. b1, 1 backward)."""
+    def build():
+        img = torch.empty((lib.vkas_mlp_chain_image_elems(C),), dtype=dtype, device=w1.device)
+        check(lib.vkas_mlp_chain_pack(_p(w1.contiguous()), _p(w2.contiguous()), _p(b1.contiguous()) if mode == 0 else None, C,
+                                      mode, _p(img), _lib.BF16, _stream()), 'mlp_chain_pack')
+        return img
+    if mode == 0:  # the forward image also depends on b1: key on (w1, w2) and stamp b1's version into the key
+        return _cached_pack_pair(w1, w2, ('chain', C, mode, dtype, b1._version, b1.data_ptr()), build)
+    return _cached_pack_pair(w1, w2, ('chain', C, mode, dtype), build)
+
+
 def pack_dw_weight(w: torch.Tensor, C: int, Cp: int, flip: int) -> torch.Tensor:
     def build():
         out = torch.empty((49 * Cp,), dtype=_FLOAT, device=w.device)
@@ -242,21 +279,62 @@ def _conv_gemm(x, geom, Bw, Np, out, mode, bias, out2, aux, colscale, rowscale, 
     return out
 
 
-def conv_wgrad(x: torch.Tensor, geom: ConvGeom, dy: torch.Tensor, Np: int, nk=None, with_bias: bool = False):
+def grad_sink(param: Optional[torch.Tensor]):
+    """(FlatBuffers, index) when ``param`` is a parameter whose .grad is a live view of a flat gradient buffer
+    (training.FlatBuffers): the backward ops then add its gradient in place - the weight-gradient GEMM accumulates into the
+    view directly when the packed layout equals the reference layout, else the unpack kernel does - and report the
+    delivery to the buffer instead of returning a tensor for autograd to add."""
+    s = getattr(param, '_vkas_sink', None) if param is not None else None
+    return s if s is not None and s[0].grad_view_ok(s[1]) else None
+
+
+def deliver_small_grads(pairs):
+    """pairs: [(parameter, gradient tensor or None)].  Gradients of parameters with a flat .grad view (grad_sink) are
+    added onto it by ONE vkas_accumulate_many launch and reported as delivered; returns the list to hand to autograd
+    (None in those places, the tensor itself otherwise)."""
+    out, todo = [], []
+    for param, g in pairs:
+        s = grad_sink(param) if g is not None else None
+        if s is None or g.dtype != _FLOAT or g.numel() != param.numel():
+            out.append(g)
+        else:
+            todo.append((s, param, g.contiguous()))
+            out.append(None)
+    for i in range(0, len(todo), 16):
+        part = todo[i:i + 16]
+        n = len(part)
+        src = (ctypes.c_void_p * n)(*[g.data_ptr() for _, _, g in part])
+        dst = (ctypes.c_void_p * n)(*[p.grad.data_ptr() for _, p, _ in part])
+        cnt = (ctypes.c_int * n)(*[g.numel() for _, _, g in part])
+        check(lib.vkas_accumulate_many(n, src, dst, cnt, _stream()), 'accumulate_many')
+    for s, _, _ in todo:
+        s[0].grad_delivered(s[1])
+    return out
+
+
+def conv_wgrad(x: torch.Tensor, geom: ConvGeom, dy: torch.Tensor, Np: int, nk=None, with_bias: bool = False,
+               x_gelu: bool = False, gw_into: Optional[torch.Tensor] = None, gb_into: Optional[torch.Tensor] = None):
     """Weight gradient in the packed (Np, K) layout; with_bias also returns the fused bias gradient (Np,): the two
-    live in one zero-filled buffer so a single memset covers both."""
+    live in one zero-filled buffer so a single memset covers both.  x_gelu: the input operand is gelu(x).
+    gw_into / gb_into: existing fp32 buffers to ACCUMULATE into (the kernels add with atomics) instead of fresh zeros."""
     K = geom.KH * geom.KW * geom.Cp
-    buf = torch.zeros((Np * K + (Np if with_bias else 0),), dtype=_FLOAT, device=x.device)
-    gw = buf[:Np * K]
-    gb = buf[Np * K:] if with_bias else None
+    n_new = (0 if gw_into is not None else Np * K) + (Np if with_bias and gb_into is None else 0)
+    buf = torch.zeros((n_new,), dtype=_FLOAT, device=x.device) if n_new else None
+    gw = gw_into if gw_into is not None else buf[:Np * K]
+    gb = None
+    if with_bias:
+        gb = gb_into if gb_into is not None else buf[n_new - Np:]
     M = geom.B * geom.Hout * geom.Wout
 
     def run():
-        check(lib.vkas_conv_gemm_wgrad(_p(x), ctypes.byref(geom), _p(dy), act_ld(dy), Np, _p(gw), _p(gb), _dt(x),
-                                       _stream()), 'conv_gemm_wgrad')
+        fn = lib.vkas_conv_gemm_wgrad_gelu if x_gelu else lib.vkas_conv_gemm_wgrad
+        check(fn(_p(x), ctypes.byref(geom), _p(dy), act_ld(dy), Np, _p(gw), _p(gb), _dt(x), _stream()), 'conv_gemm_wgrad')
         return (gw, gb) if with_bias else gw
     if x.dtype == torch.bfloat16:
-        kind = tn_kernel_name(lib.vkas_conv_gemm_kernel_id(1, ctypes.byref(geom), Np, act_ld(dy), 0))
+        kid = lib.vkas_conv_gemm_kernel_id(1, ctypes.byref(geom), Np, act_ld(dy), 0)
+        if x_gelu and kid >= 2000:  # the gelu-on-load variant exists for the generic kernel only
+            kid = lib.vkas_conv_gemm_tile(1, M, Np, K)
+        kind = tn_kernel_name(kid)
     else:
         kind = 'gemm_tn_simple'
     N, Kl = nk if nk is not None else (Np, K)
@@ -264,11 +342,43 @@ def conv_wgrad(x: torch.Tensor, geom: ConvGeom, dy: torch.Tensor, Np: int, nk=No
     return _timed(kind, x, 2.0 * M * N * Kl, M, N, Kl, run, nbytes)
 
 
-def unpack_wgrad(gw: torch.Tensor, shape4, Np: int, Cp: int) -> torch.Tensor:
+def unpack_wgrad(gw: torch.Tensor, shape4, Np: int, Cp: int, into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Packed (Np, KH, KW, Cp) weight gradient -> reference layout (N, C, KH, KW); ``into``: add onto that tensor."""
     N, C, KH, KW = shape4
-    g = torch.empty((N, C, KH, KW), dtype=_FLOAT, device=gw.device)
-    check(lib.vkas_unpack_conv_wgrad(_p(gw), _p(g), N, C, KH, KW, Np, Cp, 0, _stream()), 'unpack_conv_wgrad')
+    g = torch.empty((N, C, KH, KW), dtype=_FLOAT, device=gw.device) if into is None else into
+    check(lib.vkas_unpack_conv_wgrad(_p(gw), _p(g), N, C, KH, KW, Np, Cp, int(into is not None), _stream()),
+          'unpack_conv_wgrad')
     return g
+
+
+def conv_param_grads(x, geom, dy, Np: int, weight: torch.Tensor, bias: Optional[torch.Tensor], x_gelu: bool = False):
+    """Weight and bias gradient of an implicit-GEMM convolution / Linear for autograd: (gw, gb) in the reference layouts,
+    with None where the gradient went straight into the parameter's flat .grad view (grad_sink)."""
+    w4 = weight if weight.dim() == 4 else weight.view(weight.shape[0], weight.shape[1], 1, 1)
+    N, C, KH, KW = w4.shape
+    Cp = geom.Cp
+    nk = (N, C * KH * KW)
+    sw, sb = grad_sink(weight), grad_sink(bias)
+    same_layout = KH == 1 and KW == 1 and Np == N and Cp == C  # packed (Np, K) rows are the reference rows
+    gw_into = weight.grad.view(-1) if (sw is not None and same_layout) else None
+    gb_into = bias.grad if (sb is not None and Np == N) else None
+    r = conv_wgrad(x, geom, dy, Np, nk=nk, with_bias=bias is not None, x_gelu=x_gelu, gw_into=gw_into, gb_into=gb_into)
+    gwp, gbp = r if bias is not None else (r, None)
+    if gw_into is not None:
+        gw = None
+    elif sw is not None:
+        unpack_wgrad(gwp, (N, C, KH, KW), Np, Cp, into=weight.grad.view(N, C, KH, KW))
+        gw = None
+    else:
+        gw = unpack_wgrad(gwp, (N, C, KH, KW), Np, Cp).view(weight.shape)
+    gb = None
+    if bias is not None and gb_into is None:
+        gb = gbp[:N]
+    if sw is not None:
+        sw[0].grad_delivered(sw[1])
+    if gb_into is not None:
+        sb[0].grad_delivered(sb[1])
+    return gw, gb
 
 
 def colsum(y: torch.Tensor, n_logical: int) -> torch.Tensor:
@@ -384,13 +494,13 @@ class Conv(Function):
         out = new_act(B, Hout, Wout, Np, x)
         geom = _geom(B, Hin, Win, Hout, Wout, Cp, act_ld(x), KH, KW, stride, pad)
         conv_gemm(x, geom, Bw, Np, out, _lib.EPI_NONE, bias=pad_vector(bias, Np), nk=(N, C * KH * KW))
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x, weight, bias if bias is not None else torch.empty(0, device=x.device))
         ctx.cfg = (stride, pad, bias is not None, need_input_grad)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, bias = ctx.saved_tensors
         stride, pad, has_bias, need_input_grad = ctx.cfg
         dy = as_act(dy)
         w4 = weight if weight.dim() == 4 else weight.view(weight.shape[0], weight.shape[1], 1, 1)
@@ -398,12 +508,7 @@ class Conv(Function):
         B, Hin, Win, Cp = x.shape
         _, Hout, Wout, Np = dy.shape
         geom = _geom(B, Hin, Win, Hout, Wout, Cp, act_ld(x), KH, KW, stride, pad)
-        if has_bias:
-            gwp, gbp = conv_wgrad(x, geom, dy, Np, nk=(N, C * KH * KW), with_bias=True)
-            gb = gbp[:N]
-        else:
-            gwp, gb = conv_wgrad(x, geom, dy, Np, nk=(N, C * KH * KW)), None
-        gw = unpack_wgrad(gwp, (N, C, KH, KW), Np, Cp).view(weight.shape)
+        gw, gb = conv_param_grads(x, geom, dy, Np, weight, bias if has_bias else None)
         dx = None
         if need_input_grad and ctx.needs_input_grad[0]:
             if stride == 1:
@@ -441,6 +546,7 @@ class LayerNorm(Function):
         x, gamma, beta, stats = ctx.saved_tensors
         dx, dg, db = layernorm_bwd(x, gamma.contiguous(), beta.contiguous(), stats, as_act(dy), gamma.numel(),
                                    ctx.act_gelu)
+        dg, db = deliver_small_grads([(gamma, dg), (beta, db)])
         return dx, dg, db, None
 
 
@@ -501,6 +607,39 @@ class MultiLayerNorm(Function):
         return (dx, None, *flat)
 
 
+def _cached_pack_multi(params: Sequence[torch.Tensor], key, build):
+    """_cached_pack for an operand derived from several parameters (stacked head weights, head affine tables)."""
+    if not all(p.is_leaf and p.requires_grad for p in params):
+        return build()
+    k = (tuple(id(p) for p in params), key)
+    ent = _PACK_CACHE.get(k)
+    stamp = (tuple(p._version for p in params), _PACK_EPOCH[0], tuple(p.data_ptr() for p in params))
+    if ent is not None and ent[0] == stamp and all(r() is p for r, p in zip(ent[1], params)):
+        return ent[2]
+    out = build()
+    _PACK_CACHE[k] = (stamp, tuple(weakref.ref(p) for p in params), out)
+    return out
+
+
+def pack_head_weights(ws: Sequence[torch.Tensor], nps: Sequence[int], Cp: int, mode: int, dtype: torch.dtype) -> torch.Tensor:
+    """The heads' 3x3 weights packed side by side (head h = output channels [n0_h, n0_h + np_h)) as one GEMM operand:
+    mode 0 forward (Nt, 3, 3, Cp), mode 1 dgrad (Cp, 3, 3, Nt).  Replaces F.pad + torch.cat of the parameters."""
+    Nt = sum(nps)
+
+    def build():
+        KH, KW = ws[0].shape[2], ws[0].shape[3]
+        out = torch.empty((Nt * KH * KW * Cp,), dtype=dtype, device=ws[0].device)
+        off = 0
+        for w, np_ in zip(ws, nps):
+            N, C = w.shape[0], w.shape[1]
+            check(lib.vkas_pack_conv_weight_slice(_p(w.contiguous()), _p(out), N, C, KH, KW, np_, Cp, mode, off, Nt,
+                                                  _lib.BF16 if dtype == torch.bfloat16 else _lib.F32, _stream()),
+                  'pack_conv_weight_slice')
+            off += np_
+        return out
+    return _cached_pack_multi(list(ws), ('heads', tuple(nps), Cp, mode, dtype), build)
+
+
 class HeadsFused(Function):
     """All heads of a pass (model/upernext.py:215-223 or model/fpn.py:165-183, shared upsampled input) as ONE implicit
     GEMM whose epilogue applies each head's LayerNorm -> GELU -> Linear(C -> out_channels) per pixel: forward writes
@@ -508,8 +647,8 @@ class HeadsFused(Function):
     their gradients never reach HBM.  Backward recomputes them tile-locally (vkas_head_tail_bwd) and feeds one dz into
     the shared conv's dgrad / wgrad.  bf16 only; heads up to 224 channels and out_channels <= 4.
 
-    inputs: x (B,H,W,Cp); w_cat (sum rup8(C_h), Cin, 3, 3) / b_cat: the heads' conv weights stacked with each head padded
-    to a multiple of 8 rows; then per head gamma, beta, wproj (oc, C_h), bproj (oc).
+    inputs: x (B,H,W,Cp); then per head: conv weight (C_h, Cin, 3, 3), conv bias (C_h), gamma, beta, wproj (oc, C_h),
+    bproj (oc).  The weights are packed side by side by the pack kernel (each head padded to a multiple of 8 rows).
     outputs: per head a (B,H,W,8) fp32 activation holding the oc projected channels (columns >= oc are zero)."""
 
     @staticmethod
@@ -519,27 +658,41 @@ class HeadsFused(Function):
                 and max(out_channels) <= 4)
 
     @staticmethod
-    def forward(ctx, x, w_cat, b_cat, *params):
-        _require_cuda(x, w_cat)
+    def forward(ctx, x, *params):
+        _require_cuda(x, params[0])
         x = as_act(x)
-        n_heads = len(params) // 4
-        gammas, betas, wps, bps = params[0::4], params[1::4], params[2::4], params[3::4]
+        n_heads = len(params) // 6
+        ws, bs = params[0::6], params[1::6]
+        gammas, betas, wps, bps = params[2::6], params[3::6], params[4::6], params[5::6]
         cs = [g.numel() for g in gammas]
         ocs = [w.shape[0] for w in wps]
         nps = [rup8(c) for c in cs]
         Nt = sum(nps)
         B, H, W, Cp = x.shape
-        N, C, KH, KW = w_cat.shape
-        assert N == Nt and Cp == rup8(C) and KH == 3 and KW == 3
+        C = ws[0].shape[1]
+        assert all(tuple(w.shape) == (c, C, 3, 3) for w, c in zip(ws, cs)) and Cp == rup8(C)
         M = B * H * W
         wmax = max(nps)
         pw = 128 if wmax <= 128 else (192 if wmax <= 192 else 224)
         dev = x.device
-        hp = torch.empty((n_heads, 6 * pw + 8), dtype=_FLOAT, device=dev)
-        for h in range(n_heads):
-            check(lib.vkas_pack_head_params(_p(gammas[h].contiguous()), _p(betas[h].contiguous()),
-                                            _p(wps[h].contiguous()), _p(bps[h].contiguous()), cs[h], ocs[h], pw,
-                                            _p(hp[h]), _stream()), 'pack_head_params')
+
+        def build_hp():
+            t = torch.empty((n_heads, 6 * pw + 8), dtype=_FLOAT, device=dev)
+            for h in range(n_heads):
+                check(lib.vkas_pack_head_params(_p(gammas[h].contiguous()), _p(betas[h].contiguous()),
+                                                _p(wps[h].contiguous()), _p(bps[h].contiguous()), cs[h], ocs[h], pw,
+                                                _p(t[h]), _stream()), 'pack_head_params')
+            return t
+
+        def build_bias():
+            t = torch.zeros((Nt,), dtype=_FLOAT, device=dev)
+            off = 0
+            for b, c, np_ in zip(bs, cs, nps):
+                t[off:off + c].copy_(b.detach())
+                off += np_
+            return t
+        hp = _cached_pack_multi(list(gammas) + list(betas) + list(wps) + list(bps), ('head_params', pw), build_hp)
+        b_cat = _cached_pack_multi(list(bs), ('head_bias', tuple(nps)), build_bias)
         z = new_act(B, H, W, Nt, x)
         stats = torch.empty((n_heads, M, 2), dtype=_FLOAT, device=dev)
         proj = torch.empty((n_heads, B, H, W, 8), dtype=_FLOAT, device=dev)
@@ -551,26 +704,27 @@ class HeadsFused(Function):
             off += nps[h]
         head.params, head.stats, head.proj = hp.data_ptr(), stats.data_ptr(), proj.data_ptr()
         geom = _geom(B, H, W, H, W, Cp, act_ld(x), 3, 3, 1, 1)
-        Bw = pack_conv_weight(w_cat, Nt, Cp, 0, x.dtype)
-        conv_gemm(x, geom, Bw, Nt, z, _lib.EPI_HEAD, bias=pad_vector(b_cat, Nt), nk=(sum(cs), C * 9), head=head)
-        ctx.save_for_backward(x, w_cat, z, stats, hp)
-        ctx.meta = (cs, ocs, nps, pw)
+        Bw = pack_head_weights(ws, nps, Cp, 0, x.dtype)
+        conv_gemm(x, geom, Bw, Nt, z, _lib.EPI_HEAD, bias=b_cat, nk=(sum(cs), C * 9), head=head)
+        ctx.save_for_backward(x, z, stats, hp, *ws, *bs)
+        ctx.meta = (cs, ocs, nps, pw, C)
         return tuple(proj[h] for h in range(n_heads))
 
     @staticmethod
     def backward(ctx, *dprojs):
-        x, w_cat, z, stats, hp = ctx.saved_tensors
-        cs, ocs, nps, pw = ctx.meta
+        cs, ocs, nps, pw, C = ctx.meta
         n_heads = len(cs)
+        saved = ctx.saved_tensors
+        x, z, stats, hp = saved[:4]
+        ws, bs = saved[4:4 + n_heads], saved[4 + n_heads:4 + 2 * n_heads]
         B, H, W, Cp = x.shape
         Nt = z.shape[3]
-        N, C, KH, KW = w_cat.shape
         M = B * H * W
         dev = x.device
         dz = new_act(B, H, W, Nt, x)
         dparams = torch.empty((n_heads, 6 * pw + 8), dtype=_FLOAT, device=dev)
         nbytes = lib.vkas_head_tail_bwd_ws_bytes(M, pw)
-        ws = _ws(nbytes, dev)
+        ws_buf = _ws(nbytes, dev)
         head = _lib.HeadDesc()
         head.n_heads, head.pw = n_heads, pw
         off = 0
@@ -584,29 +738,43 @@ class HeadsFused(Function):
             dps.append(dp)
             ptrs[h] = dp.data_ptr()
         head.params, head.stats, head.proj = hp.data_ptr(), stats.data_ptr(), None
-        check(lib.vkas_head_tail_bwd(_p(z), Nt, ctypes.byref(head), ptrs, _p(dz), Nt, _p(dparams), _p(ws), nbytes, M,
+        check(lib.vkas_head_tail_bwd(_p(z), Nt, ctypes.byref(head), ptrs, _p(dz), Nt, _p(dparams), _p(ws_buf), nbytes, M,
                                      _dt(x), _stream()), 'head_tail_bwd')
         geom = _geom(B, H, W, H, W, Cp, act_ld(x), 3, 3, 1, 1)
         gwp, gbp = conv_wgrad(x, geom, dz, Nt, nk=(sum(cs), C * 9), with_bias=True)
-        gw = unpack_wgrad(gwp, (N, C, 3, 3), Nt, Cp)
+        K = 9 * Cp
+        gws, gbs, off = [], [], 0
+        for h in range(n_heads):
+            gslice = gwp[off * K:(off + nps[h]) * K]
+            sw = grad_sink(ws[h])
+            if sw is not None:  # straight into the flat gradient view
+                unpack_wgrad(gslice, (cs[h], C, 3, 3), nps[h], Cp, into=ws[h].grad)
+                sw[0].grad_delivered(sw[1])
+                gws.append(None)
+            else:
+                gws.append(unpack_wgrad(gslice, (cs[h], C, 3, 3), nps[h], Cp))
+            gbs.append(gbp[off:off + cs[h]])
+            off += nps[h]
         dx = None
         if ctx.needs_input_grad[0]:
-            Bt = pack_conv_weight(w_cat, Nt, Cp, 1, x.dtype)
+            Bt = pack_head_weights(ws, nps, Cp, 1, x.dtype)
             dx = new_act(B, H, W, Cp, x)
             g2 = _geom(B, H, W, H, W, Nt, Nt, 3, 3, 1, 1)
             conv_gemm(dz, g2, Bt, Cp, dx, _lib.EPI_NONE, nk=(C, sum(cs) * 9))
         grads = []
         for h in range(n_heads):
             d = dparams[h]
-            grads.extend([d[:cs[h]], d[pw:pw + cs[h]], d[2 * pw:6 * pw].view(4, pw)[:ocs[h], :cs[h]],
+            grads.extend([gws[h], gbs[h], d[:cs[h]], d[pw:pw + cs[h]], d[2 * pw:6 * pw].view(4, pw)[:ocs[h], :cs[h]],
                           d[6 * pw:6 * pw + ocs[h]]])
-        return (dx, gw, gbp[:N], *grads)
+        return (dx, *grads)
 
 
 class ConvNextLayer(Function):
-    """ConvNextBlockLayer.forward (model/convnext.py:29-59) as five kernels:
-    dw7x7 -> LN -> GEMM(C,4C)+GELU -> GEMM(4C,C) with the layer-scale / stochastic-depth / residual epilogue.
-    ``rowscale`` is the per-sample keep mask already divided by the keep probability (:41-53) or None."""
+    """ConvNextBlockLayer.forward (model/convnext.py:29-59): dw7x7 -> LN -> MLP with the layer-scale / stochastic-depth /
+    residual epilogue.  bf16, C % 8 == 0, C <= 256: the MLP is ONE kernel per direction (csrc/mlp_chain.hip; the 4C-wide
+    activation is written once for backward and never read back between the two matrix products); otherwise
+    GEMM(C,4C)+GELU -> GEMM(4C,C)+epilogue.  ``rowscale`` is the per-sample keep mask already divided by the keep
+    probability (:41-53) or None."""
 
     @staticmethod
     def forward(ctx, x, dw_w, dw_b, ln_g, ln_b, w1, b1, w2, b2, block_scale, rowscale):
@@ -628,26 +796,42 @@ class ConvNextLayer(Function):
         # MLP
         C4 = w1.shape[0]
         C4p = rup8(C4)
-        h = new_act(B, H, W, C4p, x)
-        g = new_act(B, H, W, C4p, x)
-        g1 = _geom(B, H, W, H, W, Cp, Cp, 1, 1, 1, 0)
-        conv_gemm(yn, g1, pack_conv_weight(w1, C4p, Cp, 0, x.dtype), C4p, h, _lib.EPI_GELU, bias=pad_vector(b1, C4p),
-                  out2=g)
         out = new_act(B, H, W, Cp, x)
         z = new_act(B, H, W, Cp, x)
-        g2 = _geom(B, H, W, H, W, C4p, C4p, 1, 1, 1, 0)
         cs = pad_vector(block_scale, Cp)
         rs = None if rowscale is None else rowscale.to(_FLOAT).contiguous()
-        conv_gemm(g, g2, pack_conv_weight(w2, Cp, C4p, 0, x.dtype), Cp, out, _lib.EPI_SCALE_RES, bias=pad_vector(b2, Cp),
-                  out2=z, aux=x, colscale=cs, rowscale=rs, rows_per_image=H * W)
-        ctx.save_for_backward(x, y, stats, yn, h, g, z, dw_w, ln_g, ln_b, w1, w2, block_scale,
-                              rs if rs is not None else torch.empty(0, device=x.device))
+        chain = C4 == 4 * C and mlp_chain_eligible(x, C)
+        if chain:
+            # one kernel: h = yn W1^T + b1 is written once (for backward), gelu(h) goes from the first matrix product
+            # into the second in registers, the layer-scale / stochastic-depth / residual epilogue follows
+            h = new_act(B, H, W, C4p, x)
+            g = None
+            img = pack_mlp_chain(w1, w2, b1, C, 0, x.dtype)
+            es = x.element_size()
+            _timed('mlp_chain_kernel<fwd>', x, 4.0 * M * C * C4, M, C, C4,
+                   lambda: check(lib.vkas_mlp_chain_fwd(_p(yn), Cp, _p(img), _p(pad_vector(b2, Cp)),
+                                                        _p(x), act_ld(x), _p(cs), _p(rs), H * W, _p(h), C4p, _p(z), Cp,
+                                                        _p(out), Cp, M, C, dt, st), 'mlp_chain_fwd'),
+                   float(M) * (4 * Cp + C4p) * es)
+        else:
+            h = new_act(B, H, W, C4p, x)
+            g = new_act(B, H, W, C4p, x)
+            g1 = _geom(B, H, W, H, W, Cp, Cp, 1, 1, 1, 0)
+            conv_gemm(yn, g1, pack_conv_weight(w1, C4p, Cp, 0, x.dtype), C4p, h, _lib.EPI_GELU, bias=pad_vector(b1, C4p),
+                      out2=g)
+            g2 = _geom(B, H, W, H, W, C4p, C4p, 1, 1, 1, 0)
+            conv_gemm(g, g2, pack_conv_weight(w2, Cp, C4p, 0, x.dtype), Cp, out, _lib.EPI_SCALE_RES,
+                      bias=pad_vector(b2, Cp), out2=z, aux=x, colscale=cs, rowscale=rs, rows_per_image=H * W)
+        empty = torch.empty(0, device=x.device)
+        ctx.save_for_backward(x, y, stats, yn, h, g if g is not None else empty, z, dw_w, ln_g, ln_b, w1, w2, block_scale,
+                              rs if rs is not None else empty, b1, dw_b, b2)
+        ctx.chain = chain
         ctx.has_rs = rs is not None
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, y, stats, yn, h, g, z, dw_w, ln_g, ln_b, w1, w2, block_scale, rs = ctx.saved_tensors
+        x, y, stats, yn, h, g, z, dw_w, ln_g, ln_b, w1, w2, block_scale, rs, b1, dw_b, b2 = ctx.saved_tensors
         rs = rs if ctx.has_rs else None
         dout = as_act(dout)
         B, H, W, Cp = x.shape
@@ -665,20 +849,29 @@ class ConvNextLayer(Function):
         ws = _ws(nbytes, dev)
         check(lib.vkas_scale_res_bwd(_p(dout), act_ld(dout), _p(z), Cp, _p(cs), _p(rs), H * W, _p(dz), Cp, _p(dscale),
                                      _p(db2), _p(ws), nbytes, M, Cp, dt, st), 'scale_res_bwd')
-        # GEMM2: z = g W2^T + b2
         g2 = _geom(B, H, W, H, W, C4p, C4p, 1, 1, 1, 0)
-        gw2 = unpack_wgrad(conv_wgrad(g, g2, dz, Cp), (C, C4, 1, 1), Cp, C4p).view(w2.shape)
-        dh = new_act(B, H, W, C4p, x)
-        gd = _geom(B, H, W, H, W, Cp, Cp, 1, 1, 1, 0)
-        conv_gemm(dz, gd, pack_conv_weight(w2, Cp, C4p, 1, x.dtype), C4p, dh, _lib.EPI_DGELU, aux=h)
-        # GEMM1: h = yn W1^T + b1 (bias gradient fused into the wgrad kernel)
         g1 = _geom(B, H, W, H, W, Cp, Cp, 1, 1, 1, 0)
-        gw1p, db1p = conv_wgrad(yn, g1, dh, C4p, with_bias=True)
-        db1 = db1p[:C4]
-        gw1 = unpack_wgrad(gw1p, (C4, C, 1, 1), C4p, Cp).view(w1.shape)
-        dyn = new_act(B, H, W, Cp, x)
-        gd1 = _geom(B, H, W, H, W, C4p, C4p, 1, 1, 1, 0)
-        conv_gemm(dh, gd1, pack_conv_weight(w1, C4p, Cp, 1, x.dtype), Cp, dyn, _lib.EPI_NONE)
+        if ctx.chain:
+            # dh = (dz W2) * gelu'(h) and dyn = dh W1 in one kernel; gelu(h) for the W2 weight gradient is applied
+            # by that GEMM's operand loader
+            dh = new_act(B, H, W, C4p, x)
+            dyn = new_act(B, H, W, Cp, x)
+            imgt = pack_mlp_chain(w1, w2, None, C, 1, x.dtype)
+            _timed('mlp_chain_kernel<bwd>', x, 4.0 * M * C * C4, M, C, C4,
+                   lambda: check(lib.vkas_mlp_chain_bwd(_p(dz), Cp, _p(imgt), _p(h), C4p, _p(dh), C4p, _p(dyn), Cp, M, C,
+                                                        dt, st), 'mlp_chain_bwd'),
+                   float(M) * (2 * Cp + 2 * C4p) * x.element_size())
+            gw2, _ = conv_param_grads(h, g2, dz, Cp, w2, None, x_gelu=True)
+        else:
+            # GEMM2: z = g W2^T + b2
+            gw2, _ = conv_param_grads(g, g2, dz, Cp, w2, None)
+            dh = new_act(B, H, W, C4p, x)
+            conv_gemm(dz, g1, pack_conv_weight(w2, Cp, C4p, 1, x.dtype), C4p, dh, _lib.EPI_DGELU, aux=h)
+        # GEMM1: h = yn W1^T + b1 (bias gradient fused into the wgrad kernel)
+        gw1, db1 = conv_param_grads(yn, g1, dh, C4p, w1, b1)
+        if not ctx.chain:
+            dyn = new_act(B, H, W, Cp, x)
+            conv_gemm(dh, g2, pack_conv_weight(w1, C4p, Cp, 1, x.dtype), Cp, dyn, _lib.EPI_NONE)
         # LayerNorm
         dy, dlg, dlb = layernorm_bwd(y, ln_g.contiguous(), ln_b.contiguous(), stats, dyn, C, False)
         # depthwise: wgrad, then dgrad (+ the residual path) in one kernel
@@ -689,8 +882,14 @@ class ConvNextLayer(Function):
         _timed('dwconv7x7_wgrad_kernel', x, 2.0 * 49 * M * C, M, Cp, 49,
                lambda: check(lib.vkas_dwconv7x7_wgrad(_p(x), act_ld(x), _p(dy), Cp, _p(gdw), _p(gdb), _p(ws), nbytes, B, H, W,
                                                       Cp, dt, st), 'dwconv7x7_wgrad'), 2.0 * M * Cp * x.element_size())
-        gdw_ref = torch.empty((C, 1, 7, 7), dtype=_FLOAT, device=dev)
-        check(lib.vkas_unpack_dw_wgrad(_p(gdw), _p(gdw_ref), C, Cp, 0, st), 'unpack_dw_wgrad')
+        sdw = grad_sink(dw_w)
+        if sdw is not None:  # unpack straight onto the flat gradient view
+            check(lib.vkas_unpack_dw_wgrad(_p(gdw), _p(dw_w.grad), C, Cp, 1, st), 'unpack_dw_wgrad')
+            sdw[0].grad_delivered(sdw[1])
+            gdw_ref = None
+        else:
+            gdw_ref = torch.empty((C, 1, 7, 7), dtype=_FLOAT, device=dev)
+            check(lib.vkas_unpack_dw_wgrad(_p(gdw), _p(gdw_ref), C, Cp, 0, st), 'unpack_dw_wgrad')
         dx = None
         if ctx.needs_input_grad[0]:
             wflip = pack_dw_weight(dw_w, C, Cp, 1)
@@ -698,7 +897,9 @@ class ConvNextLayer(Function):
             _timed('dwconv7x7_fwd_kernel', x, 2.0 * 49 * M * C, M, Cp, 49,
                    lambda: check(lib.vkas_dwconv7x7_fwd(_p(dy), Cp, _p(wflip), None, _p(dout), act_ld(dout), _p(dx), Cp, B, H,
                                                         W, Cp, dt, st), 'dwconv7x7_dgrad'), 3.0 * M * Cp * x.element_size())
-        return (dx, gdw_ref, gdb[:C], dlg, dlb, gw1, db1, gw2, db2[:C], dscale[:C].view(block_scale.shape), None)
+        gdb_, dlg, dlb, db2_, dsc = deliver_small_grads([(dw_b, gdb[:C]), (ln_g, dlg), (ln_b, dlb), (b2, db2[:C]),
+                                                         (block_scale, dscale[:C].view(block_scale.shape))])
+        return (dx, gdw_ref, gdb_, dlg, dlb, gw1, db1, gw2, db2_, dsc, None)
 
 
 class Resize(Function):

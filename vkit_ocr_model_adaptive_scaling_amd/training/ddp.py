@@ -58,19 +58,16 @@ class BucketedGradReducer:
         # like DistributedDataParallel at construction: every rank starts from rank 0's parameters, whatever its seed
         if self.world_size > 1:
             flat.broadcast_params(src=0, group=process_group)
-        for n, p in zip(flat.names, flat.params):
-            p.register_post_accumulate_grad_hook(self._make_hook(n))
+        flat.subscribe(self._on_param_grad)  # fires for autograd accumulation and for the ops' direct delivery alike
 
-    def _make_hook(self, name: str) -> Callable:
-        def hook(param):
-            b = self._param_bucket[name]
-            if not b.armed:
-                return
-            b.pending -= 1
-            if b.pending == 0:
-                b.armed = False
-                self._launch(b)
-        return hook
+    def _on_param_grad(self, name: str):
+        b = self._param_bucket[name]
+        if not b.armed:
+            return
+        b.pending -= 1
+        if b.pending == 0:
+            b.armed = False
+            self._launch(b)
 
     def arm(self, bucket_names: Sequence[str], expected: Optional[Dict[str, int]] = None):
         """Arm buckets for the next backward: each launches when all its parameters have accumulated a gradient.

@@ -11,7 +11,7 @@ parameter value (ops._PACK_CACHE) and recognise a change by the parameter's auto
 around that counter - anything through ``flat_param`` (checkpoint load, rank-0 broadcast) or through ``p.data`` (EMA
 swaps, manual init) - must be followed by ``notify_params_changed()`` (= ``ops.invalidate_packed_params()``);
 ``load_flat`` / ``broadcast_params`` below and ``FlatAdamW.step`` do it themselves."""
-from typing import Dict, Iterable, List, Tuple
+from typing import Callable, Dict, Iterable, List, Tuple
 
 import torch
 from torch import nn
@@ -50,13 +50,32 @@ class FlatBuffers:
         # which parameters received a gradient since the last zero_grad(): torch.optim.AdamW (train.py:287-298) skips
         # parameters whose .grad is None; here .grad is a persistent view, so the hook keeps the equivalent record
         self.touched = bytearray(len(self.params))
+        self._subscribers: List[Callable[[str], None]] = []
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(self._touch_hook(i))
+            # the HIP ops add weight gradients straight into this view (no temporary, no autograd add) and then call
+            # grad_delivered(i) instead of handing a tensor back to autograd: ops.grad_sink()
+            p._vkas_sink = (self, i)
 
     def _touch_hook(self, i: int):
         def hook(_param):
-            self.touched[i] = 1
+            self.grad_delivered(i)
         return hook
+
+    def subscribe(self, callback: Callable[[str], None]):
+        """callback(name) runs every time parameter ``name`` has received (a contribution to) its gradient, whether
+        through autograd's accumulation or through the ops' direct path (the bucketed reducer listens here)."""
+        self._subscribers.append(callback)
+
+    def grad_delivered(self, i: int):
+        self.touched[i] = 1
+        for cb in self._subscribers:
+            cb(self.names[i])
+
+    def grad_view_ok(self, i: int) -> bool:
+        """True while parameter i's .grad is still the view into the flat gradient buffer."""
+        p = self.params[i]
+        return p.grad is not None and p.grad.data_ptr() == self.flat_grad.data_ptr() + 4 * self.offsets[self.names[i]][0]
 
     def touched_ranges(self) -> List[Tuple[int, int]]:
         """Maximal contiguous [start, end) element ranges of parameters that got a gradient since zero_grad()."""

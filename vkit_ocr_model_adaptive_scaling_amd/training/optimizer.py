@@ -70,7 +70,8 @@ class FlatAdamW:
         # torch.optim.AdamW leaves parameters without a gradient untouched (no decay, no moment update): e.g. the
         # precise mask head under precise_enable_char_mask_head, which forward_precise never runs.  One launch per
         # contiguous run of parameters that did receive a gradient (normally the whole buffer).
-        ranges = f.touched_ranges() if all_or_none(f.touched) is None else ([(0, f.numel)] if all_or_none(f.touched) else [])
+        # (no hook fired at all = the gradients were written into the flat buffer by hand: update everything)
+        ranges = f.touched_ranges() if all_or_none(f.touched) is None else [(0, f.numel)]
         for start, end in ranges:
             off = lambda t: ctypes.c_void_p(t.data_ptr() + 4 * start)
             check(lib.vkas_adamw_step(off(f.flat_param), off(f.flat_grad), off(self.exp_avg), off(self.exp_avg_sq),
