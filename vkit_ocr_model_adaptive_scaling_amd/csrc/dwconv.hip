@@ -6,6 +6,8 @@
 // fp32 next to it.  A thread owns one 16-byte channel chunk and a 1 x 4 strip of outputs: per kernel row it
 // reads 10 input chunks and 7 weight chunks from LDS for 28 * VEC FMAs.  HBM sees each input once per
 // tile plus halo (2.08x from L2), each output once.
+#include <stdlib.h>
+
 #include "vkas_common.h"
 
 int vkas_colreduce_finalize(const float* partial, long P, int n, int ldp, float* out, int accumulate, hipStream_t st);
@@ -117,6 +119,142 @@ __global__ __launch_bounds__(256) void dwconv7x7_fwd_kernel(const T* __restrict_
       for (int c = 0; c < VEC; ++c) o[c] += a[c];
     }
     store_chunk<T>(y + pix * ldy + cb, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 forward / dgrad, "planar pair" formulation.  The kernel above spends as many VALU slots on bf16 -> fp32
+// conversions and LDS operand reads as on FMAs (a lane re-reads and re-converts every input for each 1 x 4 strip and
+// fetches its 8-channel weight vectors from LDS).  Here
+//  * the 22 x 38 halo tile of a 16 x 32 output tile x 32 channels is staged ONCE into LDS as 16 channel-PAIR planes of
+//    32-bit words (word = channels 2p, 2p+1 of one pixel; global side: 4 lanes x 16 B per pixel, plane stride = 2 mod 32
+//    words so the 4 transposing ds_write_b32 of a wave hit 32 distinct banks);
+//  * a wave works on ONE channel pair at a time: the 49 x 2 weights are wave-uniform and come from SGPRs (scalar
+//    loads), a lane owns a 1 x 8 output strip, reads 14 consecutive words per kernel row (3 ds_read_b128 + 1 b64),
+//    converts each once (2 ALU ops) and feeds 7 x 8 v_pk_fma_f32 (both channels of the pair per instruction):
+//    ~31 VALU operations per output element instead of ~55, no weight traffic in LDS, 16 accumulator registers;
+//  * results leave through LDS too (fp32, two halves of 8 planes) so that bias / the fused residual add of the dgrad
+//    and the single rounding happen on whole 16-byte channel chunks with 4 lanes x 16 B per pixel on the global side.
+constexpr int PTY = 16, PTX = 32, PIY = PTY + 6, PIX = PTX + 6;
+constexpr int PPITCH = 40;                      // words per staged row (16-byte aligned rows)
+constexpr int PPW = 898;                        // words per input plane: >= PIY * PPITCH, = 2 (mod 32)
+constexpr int POW = 2 * PTY * PTX + 4;          // words per fp32 output plane (2 per pixel): = 4 (mod 64)
+static_assert(PPW >= PIY * PPITCH && PPW % 32 == 2 && POW % 64 == 4, "plane strides");
+static_assert(8 * POW <= 16 * PPW, "an output half must fit the input planes it overwrites");
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+__global__ __launch_bounds__(256, 2) void dwconv7x7_planar_kernel(const bf16_t* __restrict__ x, long ldx,
+                                                                   const float* __restrict__ w,
+                                                                   const float* __restrict__ bias,
+                                                                   const bf16_t* __restrict__ addend, long ldadd,
+                                                                   bf16_t* __restrict__ y, long ldy, int H, int W, int Cp,
+                                                                   int cslices) {
+  __shared__ __attribute__((aligned(16))) unsigned planes[16 * PPW];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z / cslices;
+  const int c0 = (blockIdx.z - b * cslices) * 32;
+  const int x0 = blockIdx.x * PTX, y0 = blockIdx.y * PTY;
+
+  // ---- stage the halo tile: item = (pixel, 16-byte chunk); 4 words -> planes 4*chunk .. 4*chunk+3
+  for (int it = tid; it < PIY * PIX * 4; it += 256) {
+    const int chunk = it & 3, q = it >> 2;
+    const int iy = q / PIX, ix = q - iy * PIX;
+    const int gy = y0 + iy - 3, gx = x0 + ix - 3;
+    const int c = c0 + chunk * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cp)
+      v = *reinterpret_cast<const uint4*>(x + (((long)b * H + gy) * W + gx) * ldx + c);
+    unsigned* dst = planes + (chunk * 4) * PPW + iy * PPITCH + ix;
+    dst[0] = v.x;
+    dst[PPW] = v.y;
+    dst[2 * PPW] = v.z;
+    dst[3 * PPW] = v.w;
+  }
+  __syncthreads();
+
+  // ---- compute: wave = chunk (4 pairs), lane = row r, strip s (8 pixels)
+  const int r = lane >> 2, s = lane & 3;
+  f32x2 res[4][8];
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) {
+    const int P = wave * 4 + pp;          // plane = channel pair, wave-uniform
+    const int ch = c0 + 2 * P;            // first channel of the pair
+    const bool pok = ch < Cp;             // wave-uniform
+    f32x2 acc[8];
+    f32x2 bv = {0.f, 0.f};
+    if (bias && pok) bv = *reinterpret_cast<const f32x2*>(bias + ch);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bv;
+    if (pok) {
+      const unsigned* pl = planes + P * PPW + r * PPITCH + s * 8;
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        const uint4 a0 = *reinterpret_cast<const uint4*>(pl + ky * PPITCH);
+        const uint4 a1 = *reinterpret_cast<const uint4*>(pl + ky * PPITCH + 4);
+        const uint4 a2 = *reinterpret_cast<const uint4*>(pl + ky * PPITCH + 8);
+        const uint2 a3 = *reinterpret_cast<const uint2*>(pl + ky * PPITCH + 12);
+        const unsigned wd[14] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y};
+        f32x2 in[14];
+#pragma unroll
+        for (int j = 0; j < 14; ++j) {
+          in[j][0] = __builtin_bit_cast(float, wd[j] << 16);
+          in[j][1] = __builtin_bit_cast(float, wd[j] & 0xffff0000u);
+        }
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+          const f32x2 wk = *reinterpret_cast<const f32x2*>(w + (long)(ky * 7 + kx) * Cp + ch);  // wave-uniform: SGPR pair
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = __builtin_elementwise_fma(in[j + kx], wk, acc[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) res[pp][j] = acc[j];
+  }
+  __syncthreads();  // every wave is done with the input planes
+
+  // ---- results -> fp32 output planes (two halves: chunks {0,1} then {2,3}) -> 16-byte chunks of y
+  float* oplanes = reinterpret_cast<float*>(planes);
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if ((wave >> 1) == half) {
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) {
+        float* dst = oplanes + ((wave & 1) * 4 + pp) * POW + (r * PTX + s * 8) * 2;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2)
+          *reinterpret_cast<float4*>(dst + j * 2) = make_float4(res[pp][j][0], res[pp][j][1], res[pp][j + 1][0], res[pp][j + 1][1]);
+      }
+    }
+    __syncthreads();
+    for (int it = tid; it < PTY * PTX * 2; it += 256) {
+      const int chunk = it & 1, q = it >> 1;
+      const int oy = q / PTX, ox = q - oy * PTX;
+      const int gy = y0 + oy, gx = x0 + ox;
+      const int c = c0 + (half * 2 + chunk) * 8;
+      if (gy < H && gx < W && c < Cp) {
+        const float* src = oplanes + (chunk * 4) * POW + q * 2;
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float2 t = *reinterpret_cast<const float2*>(src + k * POW);
+          o[2 * k] = t.x;
+          o[2 * k + 1] = t.y;
+        }
+        const long pix = ((long)b * H + gy) * W + gx;
+        if (addend) {
+          float a[8];
+          load8(addend + pix * ldadd + c, a);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] += a[k];
+        }
+        store8(y + pix * ldy + c, o);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -244,6 +382,16 @@ extern "C" int vkas_dwconv7x7_fwd(const void* x, long ldx, const float* w, const
     if (rc) return rc;
   }
   if (B == 0) return VKAS_OK;
+  static const bool old_kernel = getenv("VKAS_DW_OLD") != nullptr;  // A/B switch
+  if (dtype == VKAS_BF16 && !old_kernel) {
+    const int cslices = (Cp + 31) / 32;
+    VKAS_CHECK((long)B * cslices <= 65535, "vkas_dwconv7x7_fwd: B*cslices too large");
+    dim3 grid((W + PTX - 1) / PTX, (H + PTY - 1) / PTY, B * cslices);
+    dwconv7x7_planar_kernel<<<grid, 256, 0, vkas_stream(stream)>>>((const bf16_t*)x, ldx, w, bias, (const bf16_t*)addend, ldadd,
+                                                                   (bf16_t*)y, ldy, H, W, Cp, cslices);
+    VKAS_LAUNCH_CHECK("dwconv7x7_planar");
+    return VKAS_OK;
+  }
   VKAS_DISPATCH_DTYPE(dtype, "vkas_dwconv7x7_fwd", {
     constexpr int CT = 4 * Vec<T>::N;
     const int cslices = (Cp + CT - 1) / CT;

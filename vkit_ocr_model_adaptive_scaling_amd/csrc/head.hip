@@ -39,7 +39,10 @@ struct HeadBwdArgs {
   const float* dproj[4];  // (M, 8) fp32 each
 };
 
-template <typename T, int NH>
+// OCM: upper bound of the heads' out_channels in this launch (1 for the rough pass: a quarter of the projection math and
+// 48 fewer accumulator registers).  The z / statistics / d(proj) loads of the NEXT row pair are issued before the current
+// pair is processed: with ~2 waves per SIMD the kernel was bound by the latency of one 16-byte load per lane per iteration.
+template <typename T, int NH, int OCM>
 __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict__ z, long ldz,
                                                             const float* __restrict__ params,
                                                             const float* __restrict__ stats, HeadBwdArgs a,
@@ -47,6 +50,8 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
                                                             long M, long rows_per_block) {
   static_assert(NH == 1 || NH == 2 || NH == 4, "lane groups per row");
   constexpr int rpi = 256 / G / NH;  // rows per sub-iteration
+  constexpr int VEC = 16 / sizeof(T);
+  typedef uint4 raw_t;               // 16 bytes of z: 8 bf16 (one per lane and row) / first half of 8 fp32
   const int gl = threadIdx.x & (G - 1);
   const int grp = threadIdx.x / G;
   const int head = grp % NH, rl = grp / NH;
@@ -67,16 +72,26 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
   }
   __syncthreads();
   const float* hp = sp + head * 6 * pw;
-  float dg[8], db[8], dwp[4][8], dbp[4] = {0.f, 0.f, 0.f, 0.f};
+  float dg[8], db[8], dwp[OCM][8], dbp[OCM];
 #pragma unroll
   for (int c = 0; c < 8; ++c) { dg[c] = 0.f; db[c] = 0.f; }
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < OCM; ++q) {
+    dbp[q] = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) dwp[q][c] = 0.f;
-  for (long m0 = mbeg; m0 < mend; m0 += (long)R * rpi) {
-    float xh[R][8], g[R][8], mean[R], rstd[R];
-    float4 dp[R];
+  }
+  // channel validity of this lane's 8 channels as a mask of multiplicative 0/1 (pad channels carry gamma = beta = 0 and
+  // Wproj = 0, so only the LayerNorm sums need it)
+  float cm[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) cm[c] = (vok && gl * 8 + c < C) ? 1.f : 0.f;
+  const float invC = 1.f / (float)C;
+
+  // in-flight loads of one row pair
+  float xr[R][8], mean[R], rstd[R];
+  float4 dp[R];
+  auto fetch = [&](long m0) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const long m = m0 + (long)r * rpi + rl;
@@ -85,62 +100,83 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
       rstd[r] = ok ? hstats[2 * m + 1] : 0.f;
       dp[r] = ok ? *reinterpret_cast<const float4*>(hdproj + m * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) xh[r][c] = 0.f;
-      if (ok && vok) load8(z + m * ldz + n0 + gl * 8, xh[r]);
+      for (int c = 0; c < 8; ++c) xr[r][c] = 0.f;
+      if (ok && vok) load8(z + m * ldz + n0 + gl * 8, xr[r]);
     }
-    float gm[8], bt[8], wp[4][8];
+  };
+  fetch(mbeg);
+  for (long m0 = mbeg; m0 < mend; m0 += (long)R * rpi) {
+    float x[R][8], mu[R], rs[R];
+    float4 d4v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      mu[r] = mean[r];
+      rs[r] = rstd[r];
+      d4v[r] = dp[r];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) x[r][c] = xr[r][c];
+    }
+    if (m0 + (long)R * rpi < mend) fetch(m0 + (long)R * rpi);  // next pair: in flight behind this pair's arithmetic
+    float gm[8], bt[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) { gm[c] = 0.f; bt[c] = 0.f; }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) wp[q][c] = 0.f;
+    int lo = gl * 8;
+    asm volatile("" : "+v"(lo));  // opaque per iteration: keeps the parameter loads in the loop (LICM would pin their VGPRs)
     if (vok) {
-      int lo = gl * 8;
-      asm volatile("" : "+v"(lo));  // opaque per iteration: keeps these loads in the loop (LICM would pin 48 VGPRs)
       load8(hp + lo, gm);
       load8(hp + pw + lo, bt);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) load8(hp + (2 + q) * pw + lo, wp[q]);
     }
-    float s1[R], s2[R];
+    float g[R][8], s1[R], s2[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const bool ok = hok && m0 + (long)r * rpi + rl < mend;
-      const float d4[4] = {dp[r].x, dp[r].y, dp[r].z, dp[r].w};
+      const float d4[4] = {d4v[r].x, d4v[r].y, d4v[r].z, d4v[r].w};
       s1[r] = 0.f;
       s2[r] = 0.f;
       if (gl == 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dbp[q] += d4[q];
+        for (int q = 0; q < OCM; ++q) dbp[q] += d4[q];
+      }
+      float act[8], gp[8], da[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float h = ok ? (x[r][c] - mu[r]) * rs[r] * cm[c] : 0.f;
+        const float u = fmaf(h, gm[c], bt[c]);
+        if constexpr (sizeof(T) == 2) {
+          float cdf, pdf;
+          gelu_parts_fast(u, cdf, pdf);
+          act[c] = fmaxf(u, -4.25f) * cdf;  // as gelu_t<T>
+          gp[c] = fmaf(u, pdf, cdf);
+        } else {
+          const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
+          const float pdf = 0.39894228040143268f * __expf(-0.5f * u * u);
+          act[c] = u * cdf;
+          gp[c] = fmaf(u, pdf, cdf);
+        }
+        x[r][c] = h;
+        da[c] = 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < OCM; ++q) {
+        float wp[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) wp[c] = 0.f;
+        if (vok) load8(hp + (2 + q) * pw + lo, wp);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          da[c] = fmaf(d4[q], wp[c], da[c]);
+          dwp[q][c] = fmaf(d4[q], act[c], dwp[q][c]);
+        }
       }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const bool cok = ok && vok && (gl * 8 + c < C);
-        const float h = cok ? (xh[r][c] - mean[r]) * rstd[r] : 0.f;
-        const float u = h * gm[c] + bt[c];
-        float cdf, pdf;
-        if constexpr (sizeof(T) == 2) {
-          gelu_parts_fast(u, cdf, pdf);
-        } else {
-          cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
-          pdf = 0.39894228040143268f * __expf(-0.5f * u * u);
-        }
-        const float act = cok ? (sizeof(T) == 2 ? fmaxf(u, -4.25f) : u) * cdf : 0.f;  // as gelu_t<T>
-        float da = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          da = fmaf(d4[q], wp[q][c], da);
-          dwp[q][c] = fmaf(d4[q], act, dwp[q][c]);
-        }
-        const float gg = cok ? da * fmaf(u, pdf, cdf) : 0.f;
-        xh[r][c] = h;
+        const float gg = ok ? da[c] * gp[c] * cm[c] : 0.f;
         g[r][c] = gg;
-        dg[c] += gg * h;
+        dg[c] = fmaf(gg, x[r][c], dg[c]);
         db[c] += gg;
         const float dxh = gg * gm[c];
         s1[r] += dxh;
-        s2[r] += dxh * h;
+        s2[r] = fmaf(dxh, x[r][c], s2[r]);
       }
     }
 #pragma unroll
@@ -150,8 +186,8 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
         s1[r] += __shfl_xor(s1[r], o, 64);
         s2[r] += __shfl_xor(s2[r], o, 64);
       }
-      s1[r] /= (float)C;
-      s2[r] /= (float)C;
+      s1[r] *= invC;
+      s2[r] *= invC;
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -159,7 +195,7 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
       if (m >= mend || !vok) continue;
       float o[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) o[c] = (gl * 8 + c < C) ? rstd[r] * (g[r][c] * gm[c] - s1[r] - xh[r][c] * s2[r]) : 0.f;
+      for (int c = 0; c < 8; ++c) o[c] = cm[c] * rs[r] * (g[r][c] * gm[c] - s1[r] - x[r][c] * s2[r]);
       store8(dz + m * lddz + n0 + gl * 8, o);
     }
   }
@@ -183,9 +219,15 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
   };
   reduce_store(dg, 0);
   reduce_store(db, pw);
+  const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int q = 0; q < 4; ++q) reduce_store(dwp[q], (2 + q) * pw);
-  float b8[8] = {dbp[0], dbp[1], dbp[2], dbp[3], 0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < 4; ++q) {
+    if (q < OCM) reduce_store(dwp[q < OCM ? q : 0], (2 + q) * pw);
+    else reduce_store(zero8, (2 + q) * pw);
+  }
+  float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < OCM; ++q) b8[q] = dbp[q];
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < 8; ++c) red[threadIdx.x * 8 + c] = b8[c];
@@ -252,14 +294,17 @@ extern "C" int vkas_head_tail_bwd(const void* z, long ldz, const vkas_head_desc*
   const long rpb = ht_rows_per_block(M);
   const long P = vkas_cdiv(M, rpb);
   const int NH = nh == 1 ? 1 : (nh == 2 ? 2 : 4);
+  int ocm = 1;
+  for (int h = 0; h < nh; ++h) ocm = hd->oc[h] > ocm ? hd->oc[h] : ocm;
+  VKAS_CHECK(ocm <= 4, "vkas_head_tail_bwd: out_channels %d > 4", ocm);
+#define VKAS_HT(NHV, OCV) \
+  head_tail_bwd_kernel<T, NHV, OCV><<<(unsigned)P, 256, 0, st>>>((const T*)z, ldz, hd->params, hd->stats, a, (T*)dz, lddz, ws, M, rpb)
   VKAS_DISPATCH_DTYPE(dtype, "vkas_head_tail_bwd", {
-    if (NH == 1)
-      head_tail_bwd_kernel<T, 1><<<(unsigned)P, 256, 0, st>>>((const T*)z, ldz, hd->params, hd->stats, a, (T*)dz, lddz, ws, M, rpb);
-    else if (NH == 2)
-      head_tail_bwd_kernel<T, 2><<<(unsigned)P, 256, 0, st>>>((const T*)z, ldz, hd->params, hd->stats, a, (T*)dz, lddz, ws, M, rpb);
-    else
-      head_tail_bwd_kernel<T, 4><<<(unsigned)P, 256, 0, st>>>((const T*)z, ldz, hd->params, hd->stats, a, (T*)dz, lddz, ws, M, rpb);
+    if (NH == 1) { if (ocm == 1) VKAS_HT(1, 1); else VKAS_HT(1, 4); }
+    else if (NH == 2) { if (ocm == 1) VKAS_HT(2, 1); else VKAS_HT(2, 4); }
+    else { if (ocm == 1) VKAS_HT(4, 1); else VKAS_HT(4, 4); }
   })
+#undef VKAS_HT
   VKAS_LAUNCH_CHECK("head_tail_bwd");
   // partial rows are (block, lane-group head) pairs: NH * PS floats per block; heads beyond n_heads are zero
   return vkas_colreduce_finalize(ws, P, nh * PS, NH * PS, dparams, 0, st);

@@ -738,8 +738,10 @@ class HeadsFused(Function):
             dps.append(dp)
             ptrs[h] = dp.data_ptr()
         head.params, head.stats, head.proj = hp.data_ptr(), stats.data_ptr(), None
-        check(lib.vkas_head_tail_bwd(_p(z), Nt, ctypes.byref(head), ptrs, _p(dz), Nt, _p(dparams), _p(ws_buf), nbytes, M,
-                                     _dt(x), _stream()), 'head_tail_bwd')
+        _timed('head_tail_bwd_kernel', x, 0.0, M, Nt, 0,
+               lambda: check(lib.vkas_head_tail_bwd(_p(z), Nt, ctypes.byref(head), ptrs, _p(dz), Nt, _p(dparams), _p(ws_buf),
+                                                    nbytes, M, _dt(x), _stream()), 'head_tail_bwd'),
+               float(M) * (2 * Nt * x.element_size() + n_heads * 40))
         geom = _geom(B, H, W, H, W, Cp, act_ld(x), 3, 3, 1, 1)
         gwp, gbp = conv_wgrad(x, geom, dz, Nt, nk=(sum(cs), C * 9), with_bias=True)
         K = 9 * Cp
