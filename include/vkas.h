@@ -12,7 +12,7 @@
  * Conventions
  *  - every function returns 0 on success, a negative VKAS_E_* code otherwise (never aborts);
  *    vkas_last_error() returns a thread-local message for the last failure.
- *  - `dtype` selects the storage type of activations: VKAS_F32 or VKAS_BF16.  Accumulation is
+ *  - `dtype` selects the storage type of activations: VKAS_F32, VKAS_BF16 or VKAS_F16.  Accumulation is
  *    always fp32.  Parameters handed over in the reference's layout are always fp32.
  *  - activations are NHWC: element (b, y, x, c) of a tensor with pixel stride `ld` (elements) lives
  *    at base[((b*H + y)*W + x)*ld + c].  `ld >= C`, `ld % 8 == 0`, bases 16-byte aligned; a channel
@@ -34,6 +34,7 @@ extern "C" {
 
 #define VKAS_F32 0
 #define VKAS_BF16 1
+#define VKAS_F16 2 /* IEEE half storage, fp32 accumulate: BASELINE.json configs[4] (fp16 inference of the Base model) */
 
 #define VKAS_OK 0
 #define VKAS_E_ARG (-1)     /* bad shape / alignment / dtype */
@@ -48,7 +49,8 @@ extern "C" {
 #define VKAS_EPI_PATCH 5      /* out scattered to non-overlapping kxk patches: dgrad of helper.py:43-58 */
 #define VKAS_EPI_HEAD 6       /* fused head tail: out = z = acc + bias (pre-LN, kept for backward); per pixel
                                * LayerNorm -> GELU -> Linear(C -> 1..4) in the epilogue; the (M, C) activation never
-                               * reaches HBM.  upernext.py:215-223 / fpn.py:165-183.  bf16 kernels only. */
+                               * reaches HBM.  upernext.py:215-223 / fpn.py:165-183.  16-bit MFMA kernels only.  out = NULL
+                               * together with head.stats = NULL: inference, z and the row statistics are not stored. */
 
 const char* vkas_last_error(void);
 int vkas_abi_version(void);
@@ -109,7 +111,10 @@ int vkas_unpack_conv_wgrad(const float* gw, float* grad, int N, int C, int KH, i
 int vkas_accumulate_many(int count, const float* const* src, float* const* dst, const int* n, void* stream);
 /* v (n) fp32 -> out (np) fp32 zero padded (bias, LayerNorm affine, block_scale) */
 int vkas_pad_vector(const float* v, float* out, int n, int np, void* stream);
-/* depthwise weight (C,1,7,7) fp32 -> (49, Cp) fp32; flip != 0 rotates the taps by 180 degrees (dgrad operand) */
+/* depthwise weight (C,1,7,7) fp32 -> vkas_dw_weight_elems(Cp) fp32: (49, Cp) taps x channels followed by the same values
+ * as (Cp/2, 7, 16) channel-pair kernel rows (scalar-load operand of the bf16 kernel); flip != 0 rotates the taps by 180
+ * degrees (dgrad operand) */
+size_t vkas_dw_weight_elems(int Cp);
 int vkas_pack_dw_weight(const float* w, float* out, int C, int Cp, int flip, void* stream);
 /* gw (49, Cp) fp32 -> grad (C,1,7,7) fp32 (+=) */
 int vkas_unpack_dw_wgrad(const float* gw, float* grad, int C, int Cp, int accumulate, void* stream);
@@ -143,7 +148,8 @@ size_t vkas_mlp_chain_image_elems(int C);
 int vkas_mlp_chain_pack(const float* w1, const float* w2, const float* b1, int C, int mode, void* img, int dtype,
                         void* stream);
 /* h = yn W1^T + b1 (stored; b1 (4C) travels inside the forward image); z = gelu(h) W2^T + b2 (stored);
- * out = x + rowscale[m / rows_per_image] * colscale * z.  b2 (C), colscale (C) fp32; rowscale (images) fp32 or NULL. */
+ * out = x + rowscale[m / rows_per_image] * colscale * z.  b2 (C), colscale (C) fp32; rowscale (images) fp32 or NULL.
+ * h = z = NULL: inference (no-grad) call, nothing is stored for a backward pass. */
 int vkas_mlp_chain_fwd(const void* yn, long ldyn, const void* img, const float* b2, const void* x, long ldx,
                        const float* colscale, const float* rowscale, int rows_per_image, void* h, long ldh, void* z,
                        long ldz, void* out, long ldo, long M, int C, int dtype, void* stream);
@@ -164,7 +170,7 @@ int vkas_colsum(const void* y, long ld, long M, int Np, float* out, int accumula
 size_t vkas_colsum_ws_bytes(long M, int Np);
 
 /* ---- depthwise 7x7: helper.py:61-73 @ convnext.py:30 ------------------------------------------- */
-/* y = dw7x7(x; w) + bias (+ addend).  w (49, Cp) fp32 (vkas_pack_dw_weight). */
+/* y = dw7x7(x; w) + bias (+ addend).  w: the vkas_dw_weight_elems(Cp) floats written by vkas_pack_dw_weight. */
 int vkas_dwconv7x7_fwd(const void* x, long ldx, const float* w, const float* bias, const void* addend, long ldadd,
                        void* y, long ldy, int B, int H, int W, int Cp, int dtype, void* stream);
 /* gw (49, Cp) and gb (Cp) fp32, overwritten */
@@ -276,6 +282,19 @@ int vkas_cross_entropy_fwd(const float* logits, const void* target, int hard, lo
                            float* loss, void* stream);
 int vkas_cross_entropy_bwd(const float* logits, const void* target, int hard, long rows, int classes, const float* dloss,
                            float* dlogits, void* stream);
+
+/* ---- inference post-processing on the device: inferencing/adaptive_scaling.py:129-188,318-396 ------------------------ */
+/* mask_logit, height (B,1,H,W) fp32 -> out_mask (B,H,W) uint8 = sigmoid >= mask_thr, out_height (B,H,W) fp32 = height where
+ * >= height_min else 0; both 0 on rows >= valid_h[b] / columns >= valid_w[b] (the divisible-by-32 padding, in feature
+ * pixels; NULL = the whole map is valid). */
+int vkas_rough_postprocess(const float* mask_logit, const float* height, int B, int H, int W, const int* valid_h,
+                           const int* valid_w, float mask_thr, float height_min, unsigned char* out_mask,
+                           float* out_height, void* stream);
+/* prob_logit (B,1,H,W), offset (B,2,H,W), angle (B,4,H,W), dist (B,4,H,W) fp32 -> out_prob (B,H,W) = sigmoid (0 in the
+ * padding), out_offset (B,H,W,2), out_angle (B,H,W,4) = softmax over the 4 logits, out_dist (B,H,W,4). */
+int vkas_precise_postprocess(const float* prob_logit, const float* offset, const float* angle, const float* dist, int B,
+                             int H, int W, const int* valid_h, const int* valid_w, float* out_prob, float* out_offset,
+                             float* out_angle, float* out_dist, void* stream);
 
 /* ---- optimizer on the flat parameter / gradient buffers: train.py:468-478 ------------------------------ */
 /* sumsq (1 double, zeroed by the call) = sum g^2 */

@@ -29,7 +29,10 @@ def timeit(fn, n=10):
 
 def main():
     p, st = ops._p, ops._stream
-    for (B, H, W, C) in ((16, 256, 256, 96), (16, 128, 128, 192), (16, 64, 64, 384), (16, 32, 32, 768), (2, 37, 45, 40)):
+    quick = '--quick' in sys.argv  # stage-0 forward / dgrad timing only (ablation builds: results are wrong by design)
+    shapes = ((16, 256, 256, 96),) if quick else ((16, 256, 256, 96), (16, 128, 128, 192), (16, 64, 64, 384), (16, 32, 32, 768),
+                                                  (2, 37, 45, 40))
+    for (B, H, W, C) in shapes:
         g = torch.Generator().manual_seed(0)
         x = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).cuda()
         dy = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).cuda()
@@ -40,6 +43,9 @@ def main():
         M = B * H * W
         fwd = lambda: check(lib.vkas_dwconv7x7_fwd(p(x), C, p(wp), p(bias), None, 0, p(y), C, B, H, W, C, 1, st()), 'fwd')
         ms = timeit(fwd)
+        if quick:
+            print(f'{os.environ.get("VKAS_LIB_PATH", "libvkas.so"):40s} fwd {ms * 1e3:7.1f} us', flush=True)
+            continue
         ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, bias, padding=3, groups=C).permute(0, 2, 3, 1)
         err = float((y.float() - ref).norm() / ref.norm())
         print(f'B={B} {H}x{W} C={C}: fwd {ms * 1e3:7.1f} us  {2 * M * C * 2 / ms / 1e9:5.2f} TB/s  rel err {err:.2e}', flush=True)

@@ -199,3 +199,51 @@ def test_loss_exports_and_shape_contract():
         ops._check_loss_maps('t', (z(2, 1, 8, 9),), (1,), z(2, 4, 5), z(2, 4, 6), 2, 2)  # score map != mask
     with pytest.raises(ValueError):
         ops._check_loss_maps('t', (z(2, 1, 8, 9),), (1,), z(2, 7, 5), z(2, 7, 5), 2, 2)  # crop leaves the map
+
+
+def test_restore_state_roundtrip_and_torch_adamw_compat(tmp_path):
+    """RestoreState files (train.py:91-96,599-605): our optimizer export loads into a real torch.optim.AdamW, a real
+    AdamW / CosineAnnealingWarmRestarts state dict loads into the flat moment buffers, and the file round-trips."""
+    import types
+    import warnings
+    from vkit_ocr_model_adaptive_scaling_amd.training import (FlatBuffers, save_restore_state, load_restore_state,
+                                                              optimizer_state_dict, load_optimizer_state_dict,
+                                                              scheduler_state_dict)
+    torch.manual_seed(0)
+    mk = lambda: torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    ref = mk()
+    topt = torch.optim.AdamW(ref.parameters(), lr=8e-4, weight_decay=0.01)
+    sch = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(topt, T_0=10, T_mult=10, eta_min=8e-6)
+    for i in range(3):
+        ref(torch.ones(2, 5) * (i + 1)).sum().backward()
+        topt.step()
+        topt.zero_grad()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            sch.step(12.25 + i)
+    m = mk()
+    fb = FlatBuffers(m.named_parameters())
+    opt = types.SimpleNamespace(flat=fb, exp_avg=torch.zeros(fb.numel), exp_avg_sq=torch.zeros(fb.numel), step_count=0,
+                                lr=1.0, betas=(0.5, 0.5), eps=1.0, weight_decay=0.5)  # stand-in with FlatAdamW's fields
+    load_optimizer_state_dict(opt, topt.state_dict())
+    assert opt.step_count == 3 and opt.lr == topt.param_groups[0]['lr'] and opt.weight_decay == 0.01
+    for i, p in enumerate(ref.parameters()):
+        s, k = fb.offsets[fb.names[i]]
+        assert torch.equal(opt.exp_avg[s:s + k], topt.state[p]['exp_avg'].reshape(-1))
+        assert torch.equal(opt.exp_avg_sq[s:s + k], topt.state[p]['exp_avg_sq'].reshape(-1))
+    # export -> a fresh torch AdamW accepts it
+    t2 = torch.optim.AdamW(mk().parameters(), lr=1.0)
+    t2.load_state_dict(optimizer_state_dict(opt))
+    assert t2.param_groups[0]['weight_decay'] == 0.01 and float(list(t2.state.values())[0]['step']) == 3.0
+    # scheduler export matches the real scheduler's state after step(14.25)
+    ours, real = scheduler_state_dict(14.25, 8e-4, 8e-6, 10, 10), sch.state_dict()
+    for k in ('T_0', 'T_i', 'T_mult', 'eta_min', 'base_lrs', 'last_epoch'):
+        assert ours[k] == real[k], k
+    assert abs(ours['T_cur'] - real['T_cur']) < 1e-12 and abs(ours['_last_lr'][0] - real['_last_lr'][0]) < 1e-12
+    # file round trip (weights_only load), parameters restored into the flat views
+    path = tmp_path / 'state_dict_7.pt'
+    save_restore_state(path, 7, ref, opt, ours)
+    rs = load_restore_state(path, m, opt)
+    assert rs.epoch_idx == 7 and set(rs.model_jit_state_dict) == set(ref.state_dict())
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert torch.equal(p, q) and p.data_ptr() == fb.flat_param.data_ptr() + 4 * fb.offsets[n][0]

@@ -15,10 +15,11 @@ from vkit_ocr_model_adaptive_scaling_amd.utils import portable_rng as prng
 
 pytestmark = pytest.mark.gpu
 
-DTYPES = [torch.float32, torch.bfloat16]
-IDS = ['f32', 'bf16']
-FWD_TOL = {torch.float32: 1e-3, torch.bfloat16: 3e-2}
-GRAD_TOL = {torch.float32: 2e-3, torch.bfloat16: 6e-2}
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+IDS = ['f32', 'bf16', 'f16']
+# fp16 (BASELINE.json configs[4]) stores 11 significant bits against bf16's 8: held to a quarter of the bf16 bounds
+FWD_TOL = {torch.float32: 1e-3, torch.bfloat16: 3e-2, torch.float16: 8e-3}
+GRAD_TOL = {torch.float32: 2e-3, torch.bfloat16: 6e-2, torch.float16: 1.5e-2}
 
 
 def seed_module(module, seed, std, block_scale=1.0):
@@ -252,9 +253,9 @@ def test_config2_tiny_backbone_640_batch4(dtype):
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=IDS)
 def test_base_model_nonsquare_vs_oracle(dtype):
-    """configs[4] ingredients that exist this round: ConvNeXt-Base widths (128..1024, neck 512, head inner 256..258) on a
-    non-square input whose sides are different multiples of 32 (stage-3 map 3 x 5): both passes, forward + one loss
-    backward, vs the oracle.  (fp16 and the inference-time resize loop are not built yet.)"""
+    """configs[4] ingredients: ConvNeXt-Base widths (128..1024, neck 512, head inner 256..258) on a non-square input whose
+    sides are different multiples of 32 (stage-3 map 3 x 5): both passes, forward + one loss backward, vs the oracle, in
+    fp32, bf16 and fp16."""
     from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
                                                            AdaptiveScalingNeckHeadType)
     model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.BASE, AdaptiveScalingNeckHeadType.UPERNEXT),
@@ -305,3 +306,45 @@ def test_packed_weight_cache_invalidation():
         assert not torch.equal(y2, y1)
         fb.load_flat(fb.flat_param * 2.0)
         assert torch.equal(m(x)[0], y1)
+
+
+def test_config5_base_fp16_mixed_shape_inference():
+    """BASELINE.json configs[4]: ConvNeXt-Base + UPerNext, fp16, B = 1, long edge 1536..2048 (x32), no-grad forward of both
+    passes (inferencing/adaptive_scaling.py:95-107,250-277 shapes).  The oracle cannot run this size in seconds, so:
+    (a) oracle parity of the same fp16 model at 192 x 288; (b) at 1536 x 1024 the size-independent properties - finite
+    outputs of the right shapes, bit-reproducible, the fp16 maps agree with the bf16 maps of the same weights to
+    bf16 accuracy, and cropping invariance away from the borders is NOT expected (global PPM pooling), so the check is
+    translation of a constant image: a constant input gives spatially constant interior outputs."""
+    from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
+                                                           AdaptiveScalingNeckHeadType)
+    model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.BASE, AdaptiveScalingNeckHeadType.UPERNEXT),
+                            compute_dtype=torch.float16)
+    seed_module(model, 63, 0.04)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda().eval()
+    x = torch.from_numpy(recipe.image(63, (1, 3, 192, 288))).float()
+    with torch.no_grad():
+        ref = O.forward_rough(sd, x, 'upernext') + O.forward_precise(sd, x, 'upernext')
+        out = model.forward_rough(x.cuda()) + model.forward_precise(x.cuda())
+    for o, r in zip(out, ref):
+        assert tuple(o.shape) == tuple(r.shape) and o.dtype == torch.float32
+        assert rel_err(o, r) < FWD_TOL[torch.float16], rel_err(o, r)
+    # full size: 1536 x 1024 (long edge 1536), one image
+    H, W = 1536, 1024
+    xl = torch.from_numpy(recipe.image(64, (1, 3, H, W))).float().cuda()
+    with torch.no_grad():
+        a = model.forward_rough(xl) + model.forward_precise(xl)
+        b = model.forward_rough(xl) + model.forward_precise(xl)
+        model.set_compute_dtype(torch.bfloat16)
+        c = model.forward_rough(xl) + model.forward_precise(xl)
+        model.set_compute_dtype(torch.float16)
+        const = model.forward_rough(torch.full((1, 3, H, W), 127.0, device='cuda'))
+    chans = (1, 1, 1, 2, 4, 4)
+    for o, o2, ob, ch in zip(a, b, c, chans):
+        assert tuple(o.shape) == (1, ch, H // 2, W // 2)
+        assert torch.isfinite(o).all()
+        assert torch.equal(o, o2), 'fp16 forward must be bit-reproducible'
+        assert rel_err(ob, o) < FWD_TOL[torch.bfloat16], rel_err(ob, o)
+    for o in const:  # constant image: interior (beyond every receptive-field border effect of the local ops) is flat
+        core = o[0, 0, 300:-300, 200:-200]
+        assert float((core - core.mean()).abs().max()) <= 2e-2 * max(1.0, float(core.abs().max()))

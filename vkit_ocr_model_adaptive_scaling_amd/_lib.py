@@ -9,9 +9,10 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int64, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvkas.so')
+# VKAS_LIB_PATH: profiling aid only (timing-only ablation builds from profiles/build_*_variants.sh)
+LIB_PATH = os.environ.get('VKAS_LIB_PATH') or os.path.join(_HERE, 'libvkas.so')
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_SCALE_RES, EPI_DGELU, EPI_ADD, EPI_PATCH, EPI_HEAD = range(7)
 LOSS_FOCAL, LOSS_DICE, LOSS_L1, LOSS_SMOOTH_L1, LOSS_L2 = range(5)
 
@@ -64,6 +65,7 @@ _SIGS = {
     'vkas_unpack_conv_wgrad': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'vkas_accumulate_many': (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), _P]),
     'vkas_pad_vector': (c_int, [_P, _P, c_int, c_int, _P]),
+    'vkas_dw_weight_elems': (c_size_t, [c_int]),
     'vkas_pack_dw_weight': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'vkas_unpack_dw_wgrad': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'vkas_image_nchw_to_nhwc8': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
@@ -111,6 +113,8 @@ _SIGS = {
     'vkas_elementwise_loss_bwd': (c_int, [c_int, _P, _P, _P, c_long, c_float, c_float, c_float, _P, _P, _P, _P]),
     'vkas_cross_entropy_fwd': (c_int, [_P, _P, c_int, c_long, c_int, _P, _P, _P]),
     'vkas_cross_entropy_bwd': (c_int, [_P, _P, c_int, c_long, c_int, _P, _P, _P]),
+    'vkas_rough_postprocess': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P]),
+    'vkas_precise_postprocess': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     'vkas_l2norm_sq': (c_int, [_P, c_long, _P, _P]),
     'vkas_adamw_step': (c_int, [_P, _P, _P, _P, c_long, _P, c_float, c_float, c_float, c_float, c_float, c_float,
                                 c_float, c_int, _P]),

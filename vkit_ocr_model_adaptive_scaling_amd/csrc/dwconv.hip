@@ -24,11 +24,15 @@ template <typename T> __device__ __forceinline__ void load_chunk(const char* p, 
 template <> __device__ __forceinline__ void load_chunk<bf16_t>(const char* p, float* v) {
   load8(reinterpret_cast<const bf16_t*>(p), v);
 }
+template <> __device__ __forceinline__ void load_chunk<f16_t>(const char* p, float* v) {
+  load8(reinterpret_cast<const f16_t*>(p), v);
+}
 template <> __device__ __forceinline__ void load_chunk<float>(const char* p, float* v) {
   load4(reinterpret_cast<const float*>(p), v);
 }
 template <typename T> __device__ __forceinline__ void store_chunk(T* p, const float* v);
 template <> __device__ __forceinline__ void store_chunk<bf16_t>(bf16_t* p, const float* v) { store8(p, v); }
+template <> __device__ __forceinline__ void store_chunk<f16_t>(f16_t* p, const float* v) { store8(p, v); }
 template <> __device__ __forceinline__ void store_chunk<float>(float* p, const float* v) { store4(p, v); }
 
 // stage the (IY x IX) halo tile around output tile origin (y0, x0), channel slice starting at c0
@@ -137,66 +141,143 @@ __global__ __launch_bounds__(256) void dwconv7x7_fwd_kernel(const T* __restrict_
 //    and the single rounding happen on whole 16-byte channel chunks with 4 lanes x 16 B per pixel on the global side.
 constexpr int PTY = 16, PTX = 32, PIY = PTY + 6, PIX = PTX + 6;
 constexpr int PPITCH = 40;                      // words per staged row (16-byte aligned rows)
-constexpr int PPW = 898;                        // words per input plane: >= PIY * PPITCH, = 2 (mod 32)
-constexpr int POW = 2 * PTY * PTX + 4;          // words per fp32 output plane (2 per pixel): = 4 (mod 64)
-static_assert(PPW >= PIY * PPITCH && PPW % 32 == 2 && POW % 64 == 4, "plane strides");
-static_assert(8 * POW <= 16 * PPW, "an output half must fit the input planes it overwrites");
+constexpr int PPW = 1026;                       // words per plane: >= PIY * PPITCH (input) and >= 2 * PTY * PTX (fp32 results), = 2 (mod 32)
+static_assert(PPW >= PIY * PPITCH && PPW >= 2 * PTY * PTX && PPW % 32 == 2, "plane stride");
+
+// Timing-only ablation switches (never set in the shipped build): 1 no FMAs, 2 no LDS row reads, 4 no weight loads,
+// 8 no halo loads, 16 no output phase.
+#ifndef DW_ABL
+#define DW_ABL 0
+#endif
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// Persistent workgroups: a workgroup walks tiles (stride gridDim.x) and fetches the NEXT tile's halo into registers before
+// it computes the current one - with one tile per workgroup the ~2 us global-load latency in front of every tile and the
+// store tail behind it were as long as the arithmetic (2 workgroups per CU cannot hide them).
 __global__ __launch_bounds__(256, 2) void dwconv7x7_planar_kernel(const bf16_t* __restrict__ x, long ldx,
                                                                    const float* __restrict__ w,
                                                                    const float* __restrict__ bias,
                                                                    const bf16_t* __restrict__ addend, long ldadd,
-                                                                   bf16_t* __restrict__ y, long ldy, int H, int W, int Cp,
-                                                                   int cslices) {
+                                                                   bf16_t* __restrict__ y, long ldy, int B, int H, int W,
+                                                                   int Cp, int cslices, int tiles_x, int tiles_y) {
   __shared__ __attribute__((aligned(16))) unsigned planes[16 * PPW];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z / cslices;
-  const int c0 = (blockIdx.z - b * cslices) * 32;
-  const int x0 = blockIdx.x * PTX, y0 = blockIdx.y * PTY;
-
-  // ---- stage the halo tile: item = (pixel, 16-byte chunk); 4 words -> planes 4*chunk .. 4*chunk+3
-  for (int it = tid; it < PIY * PIX * 4; it += 256) {
-    const int chunk = it & 3, q = it >> 2;
-    const int iy = q / PIX, ix = q - iy * PIX;
-    const int gy = y0 + iy - 3, gx = x0 + ix - 3;
-    const int c = c0 + chunk * 8;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cp)
-      v = *reinterpret_cast<const uint4*>(x + (((long)b * H + gy) * W + gx) * ldx + c);
-    unsigned* dst = planes + (chunk * 4) * PPW + iy * PPITCH + ix;
-    dst[0] = v.x;
-    dst[PPW] = v.y;
-    dst[2 * PPW] = v.z;
-    dst[3 * PPW] = v.w;
-  }
-  __syncthreads();
-
-  // ---- compute: wave = chunk (4 pairs), lane = row r, strip s (8 pixels)
   const int r = lane >> 2, s = lane & 3;
-  f32x2 res[4][8];
+  const float* wrows = w + 49L * Cp;
+  const int ntiles = tiles_x * tiles_y * B * cslices;
+  constexpr int NITEM = PIY * PIX * 4, NSTG = (NITEM + 255) / 256;
+
+  // tile index -> (channel slice, image, tile row, tile column); x fastest: neighbours share halo lines in L2
+  auto decode = [&](int t, int& b, int& c0, int& y0, int& x0) {
+    const int tx = t % tiles_x;
+    int q = t / tiles_x;
+    const int ty = q % tiles_y;
+    q /= tiles_y;
+    const int cs = q % cslices;
+    b = q / cslices;
+    c0 = cs * 32;
+    y0 = ty * PTY;
+    x0 = tx * PTX;
+  };
+  // halo tile: item = (pixel, 16-byte chunk); all loads of a thread are issued together
+  uint4 sv[NSTG];
+  auto fetch = [&](int t) {
+    int b, c0, y0, x0;
+    decode(t, b, c0, y0, x0);
 #pragma unroll
-  for (int pp = 0; pp < 4; ++pp) {
-    const int P = wave * 4 + pp;          // plane = channel pair, wave-uniform
-    const int ch = c0 + 2 * P;            // first channel of the pair
-    const bool pok = ch < Cp;             // wave-uniform
-    f32x2 acc[8];
-    f32x2 bv = {0.f, 0.f};
-    if (bias && pok) bv = *reinterpret_cast<const f32x2*>(bias + ch);
+    for (int k = 0; k < NSTG; ++k) {
+      const int it = tid + k * 256;
+      const int chunk = it & 3, q = it >> 2;
+      const int iy = q / PIX, ix = q - iy * PIX;
+      const int gy = y0 + iy - 3, gx = x0 + ix - 3;
+      const int c = c0 + chunk * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (it < NITEM && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cp && !(DW_ABL & 8))
+        v = *reinterpret_cast<const uint4*>(x + (((long)b * H + gy) * W + gx) * ldx + c);
+      sv[k] = v;
+    }
+  };
+  // 4 words of a chunk -> planes 4*chunk .. 4*chunk+3 (plane stride = 2 mod 32: the wave's writes hit 32 distinct banks)
+  auto stage = [&]() {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = bv;
-    if (pok) {
-      const unsigned* pl = planes + P * PPW + r * PPITCH + s * 8;
+    for (int k = 0; k < NSTG; ++k) {
+      const int it = tid + k * 256;
+      if (it < NITEM) {
+        const int chunk = it & 3, q = it >> 2;
+        const int iy = q / PIX, ix = q - iy * PIX;
+        unsigned* dst = planes + (chunk * 4) * PPW + iy * PPITCH + ix;
+        dst[0] = sv[k].x;
+        dst[PPW] = sv[k].y;
+        dst[2 * PPW] = sv[k].z;
+        dst[3 * PPW] = sv[k].w;
+      }
+    }
+  };
+  struct Row { uint4 a0, a1, a2; uint2 a3; };
+  auto lrow = [&](int P, int ky) {
+    const unsigned* pl = planes + P * PPW + (r + ky) * PPITCH + s * 8;
+    Row t;
+    if (DW_ABL & 2) {
+      t.a0 = make_uint4(P, ky, r, s); t.a1 = t.a0; t.a2 = t.a0; t.a3 = make_uint2(P, ky);
+      return t;
+    }
+    t.a0 = *reinterpret_cast<const uint4*>(pl);
+    t.a1 = *reinterpret_cast<const uint4*>(pl + 4);
+    t.a2 = *reinterpret_cast<const uint4*>(pl + 8);
+    t.a3 = *reinterpret_cast<const uint2*>(pl + 12);
+    return t;
+  };
+
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  fetch(t);
+  stage();
+  __syncthreads();
+  for (; t < ntiles; t += gridDim.x) {
+    int b, c0, y0, x0;
+    decode(t, b, c0, y0, x0);
+    const bool more = t + (int)gridDim.x < ntiles;
+    if (more) fetch(t + gridDim.x);  // in flight behind this tile's arithmetic
+
+    // ---- compute: wave = chunk (its 4 pair planes, which no other wave touches), lane = row r, strip s (8 pixels).
+    // Pair-row weights (see pack_dw_weight_kernel): 16 floats per (pair, ky), fetched with ONE scalar load one kernel row
+    // ahead of their use, like the 14 LDS words of the row.  The fp32 results of a pair overwrite the pair's own plane.
+    auto wrow = [&](int P, int ky) {
+      const int Pc = (c0 + 2 * P < Cp) ? (c0 >> 1) + P : 0;  // wave-uniform; an out-of-range pair reads pair 0 (unused)
+      if (DW_ABL & 4) {
+        f32x16 c;
+        for (int i = 0; i < 16; ++i) c[i] = 0.01f * (float)(i + ky);
+        return c;
+      }
+      return *reinterpret_cast<const f32x16*>(__builtin_assume_aligned(wrows + ((long)Pc * 7 + ky) * 16, 64));
+    };
+    f32x16 wn = wrow(wave * 4, 0);
+    Row rn = lrow(wave * 4, 0);
+#pragma unroll 1
+    for (int pp = 0; pp < 4; ++pp) {
+      const int P = wave * 4 + pp;          // plane = channel pair, wave-uniform
+      const int ch = c0 + 2 * P;            // first channel of the pair
+      f32x2 acc[8];
+      f32x2 bv = {0.f, 0.f};
+      if (bias && ch < Cp) bv = *reinterpret_cast<const f32x2*>(bias + ch);
 #pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = bv;
+#pragma unroll 1
       for (int ky = 0; ky < 7; ++ky) {
-        const uint4 a0 = *reinterpret_cast<const uint4*>(pl + ky * PPITCH);
-        const uint4 a1 = *reinterpret_cast<const uint4*>(pl + ky * PPITCH + 4);
-        const uint4 a2 = *reinterpret_cast<const uint4*>(pl + ky * PPITCH + 8);
-        const uint2 a3 = *reinterpret_cast<const uint2*>(pl + ky * PPITCH + 12);
-        const unsigned wd[14] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y};
+        const f32x16 wc = wn;
+        const Row rc = rn;
+        {  // next kernel row (of this pair, or row 0 of the next one): one address computation, no divergence
+          const int Pn = ky < 6 ? P : (pp < 3 ? P + 1 : P);
+          const int kn = ky < 6 ? ky + 1 : 0;
+          wn = wrow(Pn, kn);
+          rn = lrow(Pn, kn);
+        }
+        const unsigned wd[14] = {rc.a0.x, rc.a0.y, rc.a0.z, rc.a0.w, rc.a1.x, rc.a1.y, rc.a1.z, rc.a1.w,
+                                 rc.a2.x, rc.a2.y, rc.a2.z, rc.a2.w, rc.a3.x, rc.a3.y};
         f32x2 in[14];
 #pragma unroll
         for (int j = 0; j < 14; ++j) {
@@ -205,55 +286,67 @@ __global__ __launch_bounds__(256, 2) void dwconv7x7_planar_kernel(const bf16_t* 
         }
 #pragma unroll
         for (int kx = 0; kx < 7; ++kx) {
-          const f32x2 wk = *reinterpret_cast<const f32x2*>(w + (long)(ky * 7 + kx) * Cp + ch);  // wave-uniform: SGPR pair
+          const f32x2 wk = {wc[2 * kx], wc[2 * kx + 1]};
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] = __builtin_elementwise_fma(in[j + kx], wk, acc[j]);
+          for (int j = 0; j < 8; ++j) {
+            if (DW_ABL & 1) acc[j] += (kx == 0 && j == 0) ? in[j + kx] * wk : (f32x2){0.f, 0.f};
+            else acc[j] = __builtin_elementwise_fma(in[j + kx], wk, acc[j]);
+          }
         }
       }
-    }
+      float* dst = reinterpret_cast<float*>(planes + P * PPW) + (r * PTX + s * 8) * 2;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) res[pp][j] = acc[j];
-  }
-  __syncthreads();  // every wave is done with the input planes
-
-  // ---- results -> fp32 output planes (two halves: chunks {0,1} then {2,3}) -> 16-byte chunks of y
-  float* oplanes = reinterpret_cast<float*>(planes);
-#pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
-    if ((wave >> 1) == half) {
-#pragma unroll
-      for (int pp = 0; pp < 4; ++pp) {
-        float* dst = oplanes + ((wave & 1) * 4 + pp) * POW + (r * PTX + s * 8) * 2;
-#pragma unroll
-        for (int j = 0; j < 8; j += 2)
-          *reinterpret_cast<float4*>(dst + j * 2) = make_float4(res[pp][j][0], res[pp][j][1], res[pp][j + 1][0], res[pp][j + 1][1]);
-      }
+      for (int j = 0; j < 8; j += 2)
+        *reinterpret_cast<float4*>(dst + j * 2) = make_float4(acc[j][0], acc[j][1], acc[j + 1][0], acc[j + 1][1]);
     }
     __syncthreads();
-    for (int it = tid; it < PTY * PTX * 2; it += 256) {
-      const int chunk = it & 1, q = it >> 1;
-      const int oy = q / PTX, ox = q - oy * PTX;
-      const int gy = y0 + oy, gx = x0 + ox;
-      const int c = c0 + (half * 2 + chunk) * 8;
-      if (gy < H && gx < W && c < Cp) {
-        const float* src = oplanes + (chunk * 4) * POW + q * 2;
-        float o[8];
+
+    // ---- fp32 result planes -> 16-byte channel chunks of y (+ the residual): item = (pixel, chunk)
+    const float* oplanes = reinterpret_cast<const float*>(planes);
+    constexpr int NOUT = (DW_ABL & 16) ? 0 : PTY * PTX * 4 / 256;
+#pragma unroll 1
+    for (int k0 = 0; k0 < NOUT; k0 += 2) {
+      float av[2][8];
+      if (addend) {  // residual loads first, in flight together
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float2 t = *reinterpret_cast<const float2*>(src + k * POW);
-          o[2 * k] = t.x;
-          o[2 * k + 1] = t.y;
-        }
-        const long pix = ((long)b * H + gy) * W + gx;
-        if (addend) {
-          float a[8];
-          load8(addend + pix * ldadd + c, a);
+        for (int k = 0; k < 2; ++k) {
+          const int it = tid + (k0 + k) * 256;
+          const int chunk = it & 3, q = it >> 2;
+          const int oy = q / PTX, ox = q - oy * PTX;
+          const int gy = y0 + oy, gx = x0 + ox;
+          const int c = c0 + chunk * 8;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) o[k] += a[k];
+          for (int e = 0; e < 8; ++e) av[k][e] = 0.f;
+          if (gy < H && gx < W && c < Cp) load8(addend + (((long)b * H + gy) * W + gx) * ldadd + c, av[k]);
         }
-        store8(y + pix * ldy + c, o);
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int it = tid + (k0 + k) * 256;
+        const int chunk = it & 3, q = it >> 2;
+        const int oy = q / PTX, ox = q - oy * PTX;
+        const int gy = y0 + oy, gx = x0 + ox;
+        const int c = c0 + chunk * 8;
+        if (gy < H && gx < W && c < Cp) {
+          const float* src = oplanes + (chunk * 4) * PPW + q * 2;
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float2 tt = *reinterpret_cast<const float2*>(src + e * PPW);
+            o[2 * e] = tt.x;
+            o[2 * e + 1] = tt.y;
+          }
+          if (addend) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += av[k][e];
+          }
+          store8(y + (((long)b * H + gy) * W + gx) * ldy + c, o);
+        }
       }
     }
+    if (!more) break;
+    __syncthreads();  // the result planes have been read: the next halo tile may overwrite them
+    stage();
     __syncthreads();
   }
 }
@@ -382,13 +475,18 @@ extern "C" int vkas_dwconv7x7_fwd(const void* x, long ldx, const float* w, const
     if (rc) return rc;
   }
   if (B == 0) return VKAS_OK;
-  static const bool old_kernel = getenv("VKAS_DW_OLD") != nullptr;  // A/B switch
-  if (dtype == VKAS_BF16 && !old_kernel) {
+  // The planar-pair kernel is an experiment kept for A/B runs (VKAS_DW_PLANAR=1): with FMAs, conversions, LDS reads and
+  // staging all on the same two waves per SIMD it measures 300 us at stage 0 against 252 us of the kernel above
+  // (profiles/bench_dw.py; ablations in DESIGN.md): both sit on the fp32 VALU roof, not on HBM.
+  static const bool planar = getenv("VKAS_DW_PLANAR") != nullptr;
+  if (dtype == VKAS_BF16 && planar) {
     const int cslices = (Cp + 31) / 32;
-    VKAS_CHECK((long)B * cslices <= 65535, "vkas_dwconv7x7_fwd: B*cslices too large");
-    dim3 grid((W + PTX - 1) / PTX, (H + PTY - 1) / PTY, B * cslices);
+    const int tiles_x = (W + PTX - 1) / PTX, tiles_y = (H + PTY - 1) / PTY;
+    const long ntiles = (long)tiles_x * tiles_y * B * cslices;
+    VKAS_CHECK(ntiles < (1L << 30), "vkas_dwconv7x7_fwd: too many tiles");
+    const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);  // 2 persistent workgroups per CU
     dwconv7x7_planar_kernel<<<grid, 256, 0, vkas_stream(stream)>>>((const bf16_t*)x, ldx, w, bias, (const bf16_t*)addend, ldadd,
-                                                                   (bf16_t*)y, ldy, H, W, Cp, cslices);
+                                                                   (bf16_t*)y, ldy, B, H, W, Cp, cslices, tiles_x, tiles_y);
     VKAS_LAUNCH_CHECK("dwconv7x7_planar");
     return VKAS_OK;
   }

@@ -8,6 +8,8 @@ int vkas_gemm_nt_simple(const void*, const vkas_conv_geom*, const void*, int, co
 int vkas_gemm_tn_simple(const void*, const vkas_conv_geom*, const void*, long, int, float*, float*, int, int, hipStream_t);
 int vkas_gemm_nt_mfma_bf16(const void*, const vkas_conv_geom*, const void*, int, const vkas_epilogue*, hipStream_t);
 int vkas_gemm_tn_mfma_bf16(const void*, const vkas_conv_geom*, const void*, long, int, float*, float*, int, hipStream_t);
+int vkas_gemm_nt_mfma_f16(const void*, const vkas_conv_geom*, const void*, int, const vkas_epilogue*, hipStream_t);
+int vkas_gemm_tn_mfma_f16(const void*, const vkas_conv_geom*, const void*, long, int, float*, float*, int, hipStream_t);
 
 int vkas_gemm_nt_tile_choice(long M, int Np);
 int vkas_gemm_tn_tile_choice(long M, int Np, int K);
@@ -53,13 +55,14 @@ int vkas_check_geom(const char* who, const void* x, const vkas_conv_geom* g, int
 }
 
 int vkas_check_epilogue(const char* who, const vkas_epilogue* e, int Np) {
-  VKAS_CHECK(e && e->out, "%s: null output", who);
+  // the fused head tail may run without z / statistics outputs (inference: nothing is kept for a backward pass)
+  VKAS_CHECK(e && (e->out || e->mode == VKAS_EPI_HEAD), "%s: null output", who);
   VKAS_CHECK(vkas_aligned16(e->out) && e->ldo % 8 == 0, "%s: out misaligned (ldo=%ld)", who, e->ldo);
   VKAS_CHECK(e->mode >= VKAS_EPI_NONE && e->mode <= VKAS_EPI_HEAD, "%s: bad epilogue mode %d", who, e->mode);
   if (e->mode == VKAS_EPI_HEAD) {
     const vkas_head_desc* h = &e->head;
-    VKAS_CHECK(h->n_heads >= 1 && h->n_heads <= 4 && h->pw % 8 == 0 && h->pw >= 8 && h->pw <= 224 && h->params && h->stats &&
-                   h->proj && e->bias && vkas_aligned16(h->params) && vkas_aligned16(h->proj),
+    VKAS_CHECK(h->n_heads >= 1 && h->n_heads <= 4 && h->pw % 8 == 0 && h->pw >= 8 && h->pw <= 224 && h->params &&
+                   (h->stats != nullptr) == (e->out != nullptr) && h->proj && e->bias && vkas_aligned16(h->params) && vkas_aligned16(h->proj),
                "%s: bad head descriptor", who);
     for (int i = 0; i < h->n_heads; ++i)
       VKAS_CHECK(h->np[i] % 8 == 0 && h->np[i] > 0 && h->np[i] <= h->pw && h->c[i] > 0 && h->c[i] <= h->np[i] &&
@@ -68,7 +71,7 @@ int vkas_check_epilogue(const char* who, const vkas_epilogue* e, int Np) {
   }
   VKAS_CHECK((!e->bias || vkas_aligned16(e->bias)) && (!e->colscale || vkas_aligned16(e->colscale)),
              "%s: bias / colscale must be 16-byte aligned", who);
-  if (e->mode != VKAS_EPI_PATCH) VKAS_CHECK(e->ldo >= Np, "%s: ldo=%ld < Np=%d", who, e->ldo, Np);
+  if (e->mode != VKAS_EPI_PATCH && e->out) VKAS_CHECK(e->ldo >= Np, "%s: ldo=%ld < Np=%d", who, e->ldo, Np);
   if (e->mode == VKAS_EPI_GELU)
     VKAS_CHECK(e->out2 && vkas_aligned16(e->out2) && e->ldo2 >= Np && e->ldo2 % 8 == 0, "%s: GELU needs out2", who);
   if (e->mode == VKAS_EPI_SCALE_RES) {
@@ -95,9 +98,10 @@ extern "C" int vkas_conv_gemm_fwd(const void* x, const vkas_conv_geom* g, const 
     VKAS_CHECK((long)g->B * g->Hout * g->Wout == (long)g->B * epi->patch_Hs * epi->patch_Ws || g->B == 0,
                "vkas_conv_gemm_fwd: patch grid does not match the GEMM rows");
   if (epi->mode == VKAS_EPI_HEAD)
-    VKAS_CHECK(dtype == VKAS_BF16 && !force_simple() && (long)g->B * g->Hout * g->Wout >= 16384,
-               "vkas_conv_gemm_fwd: the fused head epilogue exists for the bf16 MFMA kernels (M >= 16384) only");
+    VKAS_CHECK((dtype == VKAS_BF16 || dtype == VKAS_F16) && !force_simple() && (long)g->B * g->Hout * g->Wout >= 16384,
+               "vkas_conv_gemm_fwd: the fused head epilogue exists for the 16-bit MFMA kernels (M >= 16384) only");
   if (dtype == VKAS_BF16 && !force_simple()) return vkas_gemm_nt_mfma_bf16(x, g, Bw, Np, epi, vkas_stream(stream));
+  if (dtype == VKAS_F16 && !force_simple()) return vkas_gemm_nt_mfma_f16(x, g, Bw, Np, epi, vkas_stream(stream));
   return vkas_gemm_nt_simple(x, g, Bw, Np, epi, dtype, vkas_stream(stream));
 }
 
@@ -133,6 +137,8 @@ static int conv_gemm_wgrad(const char* who, const void* x, const vkas_conv_geom*
   VKAS_CHECK(gw, "%s: null gw", who);
   if (dtype == VKAS_BF16 && !force_simple())
     return vkas_gemm_tn_mfma_bf16(x, g, dy, lddy, Np, gw, gb, x_gelu, vkas_stream(stream));
+  if (dtype == VKAS_F16 && !force_simple())
+    return vkas_gemm_tn_mfma_f16(x, g, dy, lddy, Np, gw, gb, x_gelu, vkas_stream(stream));
   return vkas_gemm_tn_simple(x, g, dy, lddy, Np, gw, gb, x_gelu, dtype, vkas_stream(stream));
 }
 

@@ -15,6 +15,30 @@
 
 #include "gemm_parts.h"
 
+// This file is compiled twice (csrc/Makefile): for bf16 storage and, with -DVKAS_MFMA_F16, for fp16 storage (config #5 of
+// BASELINE.json).  The two differ in the element type of the operands and in the MFMA opcode (same rate, fp32 accumulate);
+// data movement (LDS-DMA, swizzles, transposing reads) only sees 16-bit elements.
+#ifdef VKAS_MFMA_F16
+typedef f16_t elem_t;
+typedef f16x8 elem8;
+typedef f16x4 elem4;
+#define VKAS_MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z)
+#define VKAS_MFMA_FN(name) name##_f16
+#else
+typedef bf16_t elem_t;
+typedef bf16x8 elem8;
+typedef bf16x4 elem4;
+#define VKAS_MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
+#define VKAS_MFMA_FN(name) name##_bf16
+#endif
+
+// tile / kernel choices shared by both builds (defined once, in the bf16 build)
+int vkas_gemm_nt_tile_choice(long M, int Np);
+int vkas_gemm_tn_tile_choice(long M, int Np, int K);
+bool vkas_nt_slab_eligible(const vkas_conv_geom* g, int Np);
+bool vkas_tn_slab_eligible(const vkas_conv_geom* g, int Np, long lddy);
+bool vkas_tn_slab_n112(int Np);
+
 namespace {
 
 constexpr int BK = 64;
@@ -81,17 +105,17 @@ __device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head,
   for (int o = LPR >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
   const float rstd = rsqrtf(q / (float)C + 1e-6f);
   float pr[4] = {0.f, 0.f, 0.f, 0.f};
-  bf16_t* zout = reinterpret_cast<bf16_t*>(e.out);
+  elem_t* zout = reinterpret_cast<elem_t*>(e.out);
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int c0 = (j + LPR * i) * 8;
     if (c0 >= width) continue;
-    if (m < M) store8(zout + m * e.ldo + n0 + c0, v[i]);
+    if (m < M && zout) store8(zout + m * e.ldo + n0 + c0, v[i]);  // zout == nullptr: inference, nothing kept for backward
     float gm[8], bt[8], a[8];
     load8(hp + c0, gm);
     load8(hp + pw + c0, bt);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) a[c] = gelu_t<bf16_t>((v[i][c] - mean) * rstd * gm[c] + bt[c]);  // pad: gamma = beta = 0
+    for (int c = 0; c < 8; ++c) a[c] = gelu_t<elem_t>((v[i][c] - mean) * rstd * gm[c] + bt[c]);  // pad: gamma = beta = 0
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       float w[8];
@@ -109,9 +133,11 @@ __device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head,
     float* po = e.head.proj + ((long)head * M + m) * 8;
     *reinterpret_cast<float4*>(po) = make_float4(pr[0] + bp.x, pr[1] + bp.y, pr[2] + bp.z, pr[3] + bp.w);
     *reinterpret_cast<float4*>(po + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-    float* st = e.head.stats + ((long)head * M + m) * 2;
-    st[0] = mean;
-    st[1] = rstd;
+    if (e.head.stats) {
+      float* st = e.head.stats + ((long)head * M + m) * 2;
+      st[0] = mean;
+      st[1] = rstd;
+    }
   }
 }
 
@@ -145,7 +171,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[TM][TN], float* stage, 
       for (int i = 0; i < TM; ++i) {
         const int row = wm * TM * 16 + i * 16 + (lane & 15);
         float v[4] = {acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w};
-        store4(reinterpret_cast<bf16_t*>(st + row * PB) + cl, v);
+        store4(reinterpret_cast<elem_t*>(st + row * PB) + cl, v);
       }
     }
     __syncthreads();
@@ -158,8 +184,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[TM][TN], float* stage, 
       const int n = n0 + c8 * 8;
       if (m < M && n < n_end) {
         float v[8];
-        load8(reinterpret_cast<const bf16_t*>(st + row * PB) + c8 * 8, v);
-        epi_store8<bf16_t>(e2, m, n, v);
+        load8(reinterpret_cast<const elem_t*>(st + row * PB) + c8 * 8, v);
+        epi_store8<elem_t>(e2, m, n, v);
       }
     }
   } else {
@@ -191,8 +217,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[TM][TN], float* stage, 
 // byte offset instead of a divergent branch, and the per-K-tile address arithmetic shrinks to an add per row: the
 // main loop had ~3.8 VALU instructions per MFMA and was issue-bound; this path has < 1.
 template <int WM, int WN, int TM, int TN, bool BUF, bool HEAD>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
-                                                                  const bf16_t* __restrict__ Bw, int Np, long M, int K,
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const elem_t* __restrict__ x, vkas_conv_geom g,
+                                                                  const elem_t* __restrict__ Bw, int Np, long M, int K,
                                                                   vkas_epilogue e, unsigned a_bytes, unsigned b_bytes) {
   constexpr int NTHR = WM * WN * 64;
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -200,7 +226,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
   constexpr int ACH = BM / RSTEP;                   // A chunks per thread
   constexpr int BCH = (BN + RSTEP - 1) / RSTEP;     // B chunks per thread (last one guarded)
   static_assert(BM % RSTEP == 0, "A tile must be covered by whole staging passes");
-  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (BM + BN) * BK];
+  __shared__ __attribute__((aligned(16))) elem_t lds[2 * (BM + BN) * BK];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -224,7 +250,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
   const int sr = tid >> 3;
   int a_by[ACH], a_y[ACH], a_x[ACH];  // b*Hin, oy*stride-pad, ox*stride-pad ; a_by < 0 => row out of range
   unsigned a_base[ACH];                // BUF: byte offset of pixel (b, a_y, a_x), modulo 2^32 (a_y / a_x may be -pad)
-  const bf16_t* b_ptr[BCH];
+  const elem_t* b_ptr[BCH];
   unsigned b_base[BCH];
   bool b_ok[BCH];
 #pragma unroll
@@ -256,7 +282,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
     rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)Bw, (short)0, (int)b_bytes, 0x00020000);
   }
 
-  bf16x8 ra[ACH], rb[BCH];
+  elem8 ra[ACH], rb[BCH];
   auto load_tile = [&]() {
     const bool k_ok = kcur < K;
     if constexpr (BUF) {
@@ -267,29 +293,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
         const int iy = a_y[i] + ky, ix = a_x[i] + kx;
         const bool ok = k_ok && a_by[i] >= 0 && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_a, ok ? a_base[i] + t_off : OOB, 0, 0);
-        ra[i] = __builtin_bit_cast(bf16x8, v);
+        ra[i] = __builtin_bit_cast(elem8, v);
       }
       const unsigned kb2 = (unsigned)kcur << 1;
 #pragma unroll
       for (int i = 0; i < BCH; ++i) {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (k_ok && b_ok[i]) ? b_base[i] + kb2 : OOB, 0, 0);
-        rb[i] = __builtin_bit_cast(bf16x8, v);
+        rb[i] = __builtin_bit_cast(elem8, v);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < ACH; ++i) {
-        bf16x8 va = {0, 0, 0, 0, 0, 0, 0, 0};
+        elem8 va = {0, 0, 0, 0, 0, 0, 0, 0};
         const int iy = a_y[i] + ky, ix = a_x[i] + kx;
         if (k_ok && a_by[i] >= 0 && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win) {
           const long off = ((long)(a_by[i] + iy) * g.Win + ix) * (long)g.ldx + c_in;
-          va = *reinterpret_cast<const bf16x8*>(x + off);
+          va = *reinterpret_cast<const elem8*>(x + off);
         }
         ra[i] = va;
       }
 #pragma unroll
       for (int i = 0; i < BCH; ++i) {
-        bf16x8 vb = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (k_ok && b_ok[i]) vb = *reinterpret_cast<const bf16x8*>(b_ptr[i] + kcur);
+        elem8 vb = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (k_ok && b_ok[i]) vb = *reinterpret_cast<const elem8*>(b_ptr[i] + kcur);
         rb[i] = vb;
       }
     }
@@ -311,14 +337,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
     }
   };
   auto store_tile = [&](int buf) {
-    bf16_t* As = lds + buf * (BM + BN) * BK;
-    bf16_t* Bs = As + BM * BK;
+    elem_t* As = lds + buf * (BM + BN) * BK;
+    elem_t* Bs = As + BM * BK;
 #pragma unroll
-    for (int i = 0; i < ACH; ++i) *reinterpret_cast<bf16x8*>(As + swz_off(sr + RSTEP * i, cc)) = ra[i];
+    for (int i = 0; i < ACH; ++i) *reinterpret_cast<elem8*>(As + swz_off(sr + RSTEP * i, cc)) = ra[i];
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
       const int row = sr + RSTEP * i;
-      if (BN % RSTEP == 0 || row < BN) *reinterpret_cast<bf16x8*>(Bs + swz_off(row, cc)) = rb[i];
+      if (BN % RSTEP == 0 || row < BN) *reinterpret_cast<elem8*>(Bs + swz_off(row, cc)) = rb[i];
     }
   };
 
@@ -339,25 +365,25 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
   // Per K tile: first MFMA half | registers (tile kt+1, loaded one and a half iterations ago) -> LDS, reissue the
   // global loads for tile kt+2 | second MFMA half | barrier.  The LDS write latency and the global-load latency
   // both sit behind MFMA work instead of in front of the barrier.
-  bf16x8 fa_once[2][TM], fb_once[2][TN];
+  elem8 fa_once[2][TM], fb_once[2][TN];
   if constexpr ((ABL & 8) != 0) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        fa_once[s][i] = *reinterpret_cast<const bf16x8*>(lds + swz_off(wm * TM * 16 + i * 16 + frow, s * 4 + fchunk));
+        fa_once[s][i] = *reinterpret_cast<const elem8*>(lds + swz_off(wm * TM * 16 + i * 16 + frow, s * 4 + fchunk));
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        fb_once[s][j] = *reinterpret_cast<const bf16x8*>(lds + BM * BK + swz_off(wn * TN * 16 + j * 16 + frow, s * 4 + fchunk));
+        fb_once[s][j] = *reinterpret_cast<const elem8*>(lds + BM * BK + swz_off(wn * TN * 16 + j * 16 + frow, s * 4 + fchunk));
     }
   }
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    const bf16_t* As = lds + buf * (BM + BN) * BK;
-    const bf16_t* Bs = As + BM * BK;
+    const elem_t* As = lds + buf * (BM + BN) * BK;
+    const elem_t* Bs = As + BM * BK;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 fa[TM], fb[TN];
+      elem8 fa[TM], fb[TN];
       if constexpr ((ABL & 8) != 0) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[i] = fa_once[s][i];
@@ -366,10 +392,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
       } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          fa[i] = *reinterpret_cast<const bf16x8*>(As + swz_off(wm * TM * 16 + i * 16 + frow, s * 4 + fchunk));
+          fa[i] = *reinterpret_cast<const elem8*>(As + swz_off(wm * TM * 16 + i * 16 + frow, s * 4 + fchunk));
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          fb[j] = *reinterpret_cast<const bf16x8*>(Bs + swz_off(wn * TN * 16 + j * 16 + frow, s * 4 + fchunk));
+          fb[j] = *reinterpret_cast<const elem8*>(Bs + swz_off(wn * TN * 16 + j * 16 + frow, s * 4 + fchunk));
       }
       if constexpr ((ABL & 16) != 0) {
 #pragma unroll
@@ -382,7 +408,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = VKAS_MFMA16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
       }
       if (s == 0 && kt + 1 < nk) {
@@ -412,7 +438,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const bf16_t*
 // this kernel cuts the bytes instead of chasing issue slots:
 //  * an M tile is 256 consecutive pixels of ONE image row.  For input row ky and a 64-channel block, the 258-pixel
 //    slab (tile + one halo pixel each side) is staged once and serves the three kx taps as row-shifted fragment
-//    reads: A traffic / 3.  K is walked as (ky, channel block, kx); the weights keep their [n][ky][kx][c] layout.
+//    reads: A traffic / 3.  K is walked as (channel block, ky, kx); the weights keep their [n][ky][kx][c] layout.
 //  * operands go global -> LDS directly (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass.  The
 //    LDS image of one wave instruction is 8 rows x 128 B, lane-linear; the XOR swizzle the fragment reads expect is
 //    applied to the per-lane SOURCE chunk.  Out-of-range lanes (zero padding, channel / N tails) use an offset
@@ -425,14 +451,14 @@ constexpr int SLAB = 264 * BK;  // rows 0..255 tile pixels, 256 / 257 left / rig
 
 // TN = MFMA column tiles per wave (block N extent 32 * TN); BNT = N extent the launch spaces its N tiles by (>= 32 * TN:
 // a fused-head launch sized for its widest head runs the narrower heads with a smaller TN, see the kernel below).
-typedef __attribute__((address_space(3))) bf16_t lds_bf16;
-typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
+typedef __attribute__((address_space(3))) elem_t lds_elem;
+typedef __attribute__((address_space(3))) elem8 lds_elem8;
 
 template <int TN, bool HEAD, int BNT>
-__device__ __forceinline__ void conv3x3_slab_body(const bf16_t* __restrict__ x, const vkas_conv_geom& g,
-                                                  const bf16_t* __restrict__ Bw, int Np, long M, int K,
+__device__ __forceinline__ void conv3x3_slab_body(const elem_t* __restrict__ x, const vkas_conv_geom& g,
+                                                  const elem_t* __restrict__ Bw, int Np, long M, int K,
                                                   const vkas_epilogue& e, unsigned a_bytes, unsigned b_bytes,
-                                                  lds_bf16* lds, unsigned tile, unsigned ntile_n) {
+                                                  lds_elem* lds, unsigned tile, unsigned ntile_n) {
   constexpr int WM = 4, WN = 2, TM = 4;
   constexpr int BM = 256, BN = WN * TN * 16;
   constexpr int BT = BN * BK;
@@ -483,7 +509,7 @@ __device__ __forceinline__ void conv3x3_slab_body(const bf16_t* __restrict__ x, 
   auto issue_a = [&](int part, int ky, int cb, int sb) {
     const bool row_ok = (unsigned)(oy - 1 + ky) < (unsigned)H;
     const unsigned step_off = (unsigned)ky * row_pitch + (unsigned)cb * 128u;
-    lds_bf16* dst = lds + sb * SLAB;
+    lds_elem* dst = lds + sb * SLAB;
     if (part < 2) {
       const bool ok = row_ok && cb * 64 + cl * 8 < Cp;
       unsigned base = a_base;
@@ -505,7 +531,7 @@ __device__ __forceinline__ void conv3x3_slab_body(const bf16_t* __restrict__ x, 
   auto issue_b = [&](int ky, int kx, int cb, int slot) {
     const unsigned step_off = ((unsigned)((ky * 3 + kx) * Cp) + (unsigned)cb * 64u) * 2u;
     const bool c_ok = cb * 64 + cl * 8 < Cp;
-    lds_bf16* dst = lds + 2 * SLAB + slot * BT;
+    lds_elem* dst = lds + 2 * SLAB + slot * BT;
     unsigned base = b_base;
     asm volatile("" : "+v"(base));
 #pragma unroll
@@ -550,9 +576,13 @@ __device__ __forceinline__ void conv3x3_slab_body(const bf16_t* __restrict__ x, 
   auto step = [&](auto sbc, int s) {
     constexpr int sb = decltype(sbc)::value;
     const bool more = s + 1 < NS;
-    int ky1 = ky, cb1 = cb + 1;
-    if (cb1 == NCB) { cb1 = 0; ky1 = ky + 1; }
-    const lds_bf16* As = lds + sb * SLAB;
+    // K order (channel block, ky, kx): the three input rows of a channel block are staged in consecutive steps, so row y
+    // of block cb is fetched by the tiles of rows y+1, y, y-1 within ~3 steps of each other and the later two hit L2.
+    // With ky outermost (round 1) those uses were a third of the K loop apart and the row had left the 4 MB L2 in
+    // between: rocprofv3 showed 13.3 GB per dgrad launch against ~5 GB of operands.
+    int ky1 = ky + 1, cb1 = cb;
+    if (ky1 == 3) { ky1 = 0; cb1 = cb + 1; }
+    const lds_elem* As = lds + sb * SLAB;
     auto sub = [&](auto kxc) {
       constexpr int kx = decltype(kxc)::value;
       constexpr int NA = kx == 0 ? 3 : (kx == 1 ? 2 : 0);
@@ -567,8 +597,8 @@ __device__ __forceinline__ void conv3x3_slab_body(const bf16_t* __restrict__ x, 
         }
       };
       // ---- READ phase: share of the next slab, weight tile two sub-steps ahead, this sub-step's fragments
-      const lds_bf16* Bs = lds + 2 * SLAB + kx * BT;
-      bf16x8 fa[2][TM], fb[2][TN];
+      const lds_elem* Bs = lds + 2 * SLAB + kx * BT;
+      elem8 fa[2][TM], fb[2][TN];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -577,11 +607,11 @@ __device__ __forceinline__ void conv3x3_slab_body(const bf16_t* __restrict__ x, 
           int sr = r + kx - 1;                         // slab row of the tap's pixel
           if (kx == 0 && i == 0) sr = (sr < 0) ? 256 : sr;
           if (kx == 2 && i == TM - 1) sr = (sr > 255) ? 257 : sr;
-          fa[h][i] = *(const lds_bf16x8*)(As + swz_off(sr, h * 4 + fchunk));
+          fa[h][i] = *(const lds_elem8*)(As + swz_off(sr, h * 4 + fchunk));
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          fb[h][j] = *(const lds_bf16x8*)(Bs + swz_off(wn * TN * 16 + j * 16 + frow, h * 4 + fchunk));
+          fb[h][j] = *(const lds_elem8*)(Bs + swz_off(wn * TN * 16 + j * 16 + frow, h * 4 + fchunk));
       }
       asm volatile("" ::: "memory");  // fragment reads first: their latency hides behind the DMA issue
       if constexpr ((ABL & 1) == 0) {
@@ -613,7 +643,7 @@ __device__ __forceinline__ void conv3x3_slab_body(const bf16_t* __restrict__ x, 
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[h][j], fa[h][i], acc[i][j], 0, 0, 0);
+              acc[i][j] = VKAS_MFMA16(fb[h][j], fa[h][i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
       }
       if (grp == 0) retire();
@@ -637,11 +667,11 @@ __device__ __forceinline__ void conv3x3_slab_body(const bf16_t* __restrict__ x, 
 }
 
 template <int TN, bool HEAD>
-__global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
-                                                                const bf16_t* __restrict__ Bw, int Np, long M, int K,
+__global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const elem_t* __restrict__ x, vkas_conv_geom g,
+                                                                const elem_t* __restrict__ Bw, int Np, long M, int K,
                                                                 vkas_epilogue e, unsigned a_bytes, unsigned b_bytes) {
   constexpr int BN = 32 * TN;
-  __shared__ __attribute__((aligned(1024))) bf16_t lds[2 * SLAB + 3 * BN * BK];
+  __shared__ __attribute__((aligned(1024))) elem_t lds[2 * SLAB + 3 * BN * BK];
   // tile order: as in gemm_nt_mfma_kernel (contiguous runs per XCD, N tiles fastest)
   const unsigned ntile_n = HEAD ? (unsigned)e.head.n_heads : (unsigned)((Np + BN - 1) / BN);
   const unsigned total = gridDim.x;
@@ -652,11 +682,11 @@ __global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const bf16_t* __
     // the launch is sized for its widest head (<= 224 columns); heads of <= 192 columns run the 6-tile body: 1/7 fewer
     // MFMAs and weight bytes for three of the four precise heads
     if (e.head.np[tile % ntile_n] <= 192) {
-      conv3x3_slab_body<6, true, BN>(x, g, Bw, Np, M, K, e, a_bytes, b_bytes, (lds_bf16*)lds, tile, ntile_n);
+      conv3x3_slab_body<6, true, BN>(x, g, Bw, Np, M, K, e, a_bytes, b_bytes, (lds_elem*)lds, tile, ntile_n);
       return;
     }
   }
-  conv3x3_slab_body<TN, HEAD, BN>(x, g, Bw, Np, M, K, e, a_bytes, b_bytes, (lds_bf16*)lds, tile, ntile_n);
+  conv3x3_slab_body<TN, HEAD, BN>(x, g, Bw, Np, M, K, e, a_bytes, b_bytes, (lds_elem*)lds, tile, ntile_n);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -665,13 +695,13 @@ constexpr int TN_ROWS = 64;  // reduction rows per iteration
 // k-permuted transposed fragment: elements 0..3 <- rows mbase + 4g + {0..3}, elements 4..7 <- rows mbase + 16 + 4g + {0..3}
 // (the same permutation is used for both MFMA operands, so the sum over k is unchanged)
 template <int LD>
-__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int mbase, int colbase, int lane) {
+__device__ __forceinline__ elem8 tr_frag(const elem_t* tile, int mbase, int colbase, int lane) {
   const int g4 = lane >> 4, idx = lane & 15, q = idx >> 2, p = idx & 3;
-  const bf16_t* a0 = tile + (mbase + 4 * g4 + q) * LD + colbase + 4 * p;
-  const bf16_t* a1 = a0 + 16 * LD;
+  const elem_t* a0 = tile + (mbase + 4 * g4 + q) * LD + colbase + 4 * p;
+  const elem_t* a1 = a0 + 16 * LD;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
-  union { struct { s16x4 l, h; } s; bf16x8 v; } u;
+  union { struct { s16x4 l, h; } s; elem8 v; } u;
   u.s.l = lo;
   u.s.h = hi;
   return u.v;
@@ -684,8 +714,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int mbase, int col
 // XG: the x operand is gelu(x) (the W2 weight gradient of the fused ConvNeXt MLP, whose forward keeps only the
 // pre-activation): applied to the staged registers on their way into LDS, once per element and N tile.
 template <int WN, int WK, int TNn, int TK, bool BUF, bool XG>
-__global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
-                                                                  const bf16_t* __restrict__ dy, long lddy, int Np,
+__global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const elem_t* __restrict__ x, vkas_conv_geom g,
+                                                                  const elem_t* __restrict__ dy, long lddy, int Np,
                                                                   long M, int K, long rows_per_split,
                                                                   float* __restrict__ gw, float* __restrict__ gb,
                                                                   unsigned x_bytes, unsigned dy_bytes) {
@@ -699,7 +729,7 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
   constexpr int XCH = TN_ROWS / XSTEP;                     // x chunks per thread
   static_assert(NTHR % CPRX == 0 && TN_ROWS % XSTEP == 0, "x tile must be covered by whole staging passes");
   constexpr int TILE = TN_ROWS * (LDD + LDX);
-  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * TILE];
+  __shared__ __attribute__((aligned(16))) elem_t lds[2 * TILE];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -722,7 +752,7 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
 
   // dy staging: chunk index tid + NTHR*i -> (row, col)
   int d_row[DCH], d_lds[DCH];
-  const bf16_t* d_ptr[DCH];
+  const elem_t* d_ptr[DCH];
   unsigned d_off[DCH];  // BUF: running byte offset of this chunk
   bool d_ok[DCH];
 #pragma unroll
@@ -764,7 +794,7 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
   const unsigned d_step = (unsigned)((long)TN_ROWS * lddy * 2);
   const unsigned c_in2 = (unsigned)c_in << 1;
 
-  bf16x8 rd[DCH], rx[XCH];
+  elem8 rd[DCH], rx[XCH];
   long mcur = mbeg;
   auto load_tile = [&]() {
     constexpr unsigned OOB = 0xFFFFFFF0u;  // beyond any descriptor: the buffer load returns zeros
@@ -772,11 +802,11 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
     for (int i = 0; i < DCH; ++i) {
       const bool ok = d_ok[i] && mcur + d_row[i] < mend;
       if constexpr (BUF) {
-        rd[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_d, ok ? d_off[i] : OOB, 0, 0));
+        rd[i] = __builtin_bit_cast(elem8, __builtin_amdgcn_raw_buffer_load_b128(rs_d, ok ? d_off[i] : OOB, 0, 0));
         d_off[i] += d_step;
       } else {
-        bf16x8 vd = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ok) vd = *reinterpret_cast<const bf16x8*>(d_ptr[i]);
+        elem8 vd = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) vd = *reinterpret_cast<const elem8*>(d_ptr[i]);
         rd[i] = vd;
         d_ptr[i] += (long)TN_ROWS * lddy;
       }
@@ -787,10 +817,10 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
       const bool ok = k_ok && mcur + xr + XSTEP * i < mend && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
       if constexpr (BUF) {
         const unsigned off = ((((unsigned)(r_b[i] * g.Hin + iy) * (unsigned)g.Win + (unsigned)ix) * (unsigned)g.ldx) << 1) + c_in2;
-        rx[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? off : OOB, 0, 0));
+        rx[i] = __builtin_bit_cast(elem8, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? off : OOB, 0, 0));
       } else {
-        bf16x8 vx = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ok) vx = *reinterpret_cast<const bf16x8*>(x + (((long)r_b[i] * g.Hin + iy) * g.Win + ix) * (long)g.ldx + c_in);
+        elem8 vx = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) vx = *reinterpret_cast<const elem8*>(x + (((long)r_b[i] * g.Hin + iy) * g.Win + ix) * (long)g.ldx + c_in);
         rx[i] = vx;
       }
       r_x[i] += TN_ROWS;  // advance this row by TN_ROWS output pixels, no divisions
@@ -805,19 +835,19 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
     mcur += TN_ROWS;
   };
   auto store_tile = [&](int buf) {
-    bf16_t* Ds = lds + buf * TILE;
-    bf16_t* Xs = Ds + TN_ROWS * LDD;
+    elem_t* Ds = lds + buf * TILE;
+    elem_t* Xs = Ds + TN_ROWS * LDD;
 #pragma unroll
     for (int i = 0; i < DCH; ++i)
-      if ((TN_ROWS * CPRD) % NTHR == 0 || tid + NTHR * i < TN_ROWS * CPRD) *reinterpret_cast<bf16x8*>(Ds + d_lds[i]) = rd[i];
+      if ((TN_ROWS * CPRD) % NTHR == 0 || tid + NTHR * i < TN_ROWS * CPRD) *reinterpret_cast<elem8*>(Ds + d_lds[i]) = rd[i];
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
-      bf16x8 v = rx[i];
+      elem8 v = rx[i];
       if constexpr (XG) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (bf16_t)gelu_t<bf16_t>((float)v[q]);
+        for (int q = 0; q < 8; ++q) v[q] = (elem_t)gelu_t<elem_t>((float)v[q]);
       }
-      *reinterpret_cast<bf16x8*>(Xs + (xr + XSTEP * i) * LDX + xc * 8) = v;
+      *reinterpret_cast<elem8*>(Xs + (xr + XSTEP * i) * LDX + xc * 8) = v;
     }
   };
 
@@ -842,11 +872,11 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
   __syncthreads();
   for (int it = 0; it < nit; ++it) {
     const int buf = it & 1;
-    const bf16_t* Ds = lds + buf * TILE;
-    const bf16_t* Xs = Ds + TN_ROWS * LDD;
+    const elem_t* Ds = lds + buf * TILE;
+    const elem_t* Xs = Ds + TN_ROWS * LDD;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 fd[TNn], fx[TK];
+      elem8 fd[TNn], fx[TK];
 #pragma unroll
       for (int i = 0; i < TNn; ++i) fd[i] = tr_frag<LDD>(Ds, s * 32, wn * TNn * 16 + i * 16, lane);
 #pragma unroll
@@ -856,7 +886,7 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const bf16_t*
       for (int i = 0; i < TNn; ++i)
 #pragma unroll
         for (int j = 0; j < TK; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[i], fx[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = VKAS_MFMA16(fd[i], fx[j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       if (do_bias) {
 #pragma unroll
@@ -919,18 +949,18 @@ constexpr int WG_BUF = WG_DY + WG_X;
 typedef s16x4 __attribute__((address_space(3))) * wg_lds_ptr;
 // k-permuted transposed fragment (see tr_frag) from two byte addresses inside the LDS window: elements 0..3 <- a0,
 // elements 4..7 <- a1 (16 rows further)
-__device__ __forceinline__ bf16x8 wg_frag2(unsigned a0, unsigned a1) {
+__device__ __forceinline__ elem8 wg_frag2(unsigned a0, unsigned a1) {
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_ptr)(uintptr_t)a0);
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_ptr)(uintptr_t)a1);
-  union { struct { s16x4 l, h; } s; bf16x8 v; } u;
+  union { struct { s16x4 l, h; } s; elem8 v; } u;
   u.s.l = lo;
   u.s.h = hi;
   return u.v;
 }
 
 template <int TNn>
-__global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const bf16_t* __restrict__ x, vkas_conv_geom g,
-                                                                 const bf16_t* __restrict__ dy, long lddy, int Np,
+__global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const elem_t* __restrict__ x, vkas_conv_geom g,
+                                                                 const elem_t* __restrict__ dy, long lddy, int Np,
                                                                  long M, int K, int chunks_per_split,
                                                                  float* __restrict__ gw, float* __restrict__ gb,
                                                                  unsigned x_bytes, unsigned dy_bytes) {
@@ -940,7 +970,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const bf16_t* _
   constexpr int BNn = TNn * 16, PD = BNn * 2;  // dy row pitch in bytes
   constexpr int DWI = WG_ROWS * PD / 1024;     // dy wave instructions per chunk (16 or 14)
   constexpr unsigned OOB = 0xFFFFFFF0u;
-  __shared__ __attribute__((aligned(1024))) bf16_t lds[4 * WG_BUF];
+  __shared__ __attribute__((aligned(1024))) elem_t lds[4 * WG_BUF];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -953,9 +983,14 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const bf16_t* _
   const unsigned q8 = total >> 3, r8 = total & 7u;
   const unsigned work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
   const unsigned tile = work % tiles;
-  const int n0 = (int)(tile % ntn) * BNn;
-  const int ky = (int)((tile / ntn) % 3u);
-  const int cb = (int)(tile / (ntn * 3u));
+  // within a split: n tile slowest.  An XCD runs 32 workgroups at a time, i.e. about half the 27 - 63 tiles of a split:
+  // with the 9 (ky, channel block) tiles of an n tile adjacent, the co-resident set shares each dy slice 9 ways and each x
+  // slab 3 - 4 ways through L2; with the n tiles fastest (round 1) every slice and slab was fetched by both halves
+  // (rocprofv3: 14.2 GB per launch against 4.1 GB of operands).
+  const unsigned per_n = 3u * ncb;
+  const int n0 = (int)(tile / per_n) * BNn;
+  const int ky = (int)((tile % per_n) % 3u);
+  const int cb = (int)((tile % per_n) / 3u);
   const long total_chunks = M / WG_ROWS;
   const long c_beg = (long)(work / tiles) * chunks_per_split;
   const int nchunks = (int)((c_beg + chunks_per_split <= total_chunks ? chunks_per_split : total_chunks - c_beg));
@@ -1008,8 +1043,8 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const bf16_t* _
     i_x = rem - i_y * W;
   }
   auto issue_chunk = [&](int buf) {  // 5 instructions per wave
-    bf16_t* Ds = lds + buf * WG_BUF;
-    bf16_t* Xs = Ds + WG_DY;
+    elem_t* Ds = lds + buf * WG_BUF;
+    elem_t* Xs = Ds + WG_DY;
     const unsigned d_base = (unsigned)(ic * WG_ROWS * lddy) * 2u;
     const int iy = i_y + ky - 1;
     const bool row_ok = (unsigned)iy < (unsigned)H;
@@ -1089,7 +1124,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const bf16_t* _
   for (int t = 0; t < nchunks; ++t) {
     const unsigned bufb = lds_base + (unsigned)((t & 3) * WG_BUF * 2);
     // ---- READ phase
-    bf16x8 fd[2][TNn], fx[2][TK];
+    elem8 fd[2][TNn], fx[2][TK];
 #pragma unroll
     for (int i = 0; i < TNn; ++i) {
       const unsigned a = bufb + d_addr[i];
@@ -1135,7 +1170,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const bf16_t* _
         for (int i = 0; i < TNn; ++i)
 #pragma unroll
           for (int j = 0; j < TK; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[h][i], fx[h][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = VKAS_MFMA16(fd[h][i], fx[h][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     }
     if (do_bias) {
@@ -1192,8 +1227,8 @@ static void launch_nt(const void* x, const vkas_conv_geom* g, const void* Bw, in
   const long b_bytes = (long)Np * K * 2;
   static const bool no_buf = getenv("VKAS_NT_NOBUF") != nullptr;
   const bool buf = !no_buf && a_bytes < 0xFFFFFFF0L && b_bytes < 0xFFFFFFF0L;
-  const bf16_t* xp = (const bf16_t*)x;
-  const bf16_t* bp = (const bf16_t*)Bw;
+  const elem_t* xp = (const elem_t*)x;
+  const elem_t* bp = (const elem_t*)Bw;
   const unsigned ab = buf ? (unsigned)a_bytes : 0u, bb = buf ? (unsigned)b_bytes : 0u;
   if (e->mode == VKAS_EPI_HEAD) {
     if constexpr (WM * WN == 8) {  // the fused head epilogue is instantiated for the 8-wave tiles only
@@ -1207,6 +1242,7 @@ static void launch_nt(const void* x, const vkas_conv_geom* g, const void* Bw, in
   }
 }
 
+#ifndef VKAS_MFMA_F16
 // Tile choice of the NT kernel: returns 1 for the 4-wave 128x128 tile, else the N extent (128 / 192 / 224) of the
 // 8-wave 256-row tile.  256-row tiles once there is enough work to fill the chip with them; N extent = the candidate
 // with the least zero padding (ties -> wider tile, fewer re-reads of A).
@@ -1251,7 +1287,9 @@ bool vkas_tn_slab_eligible(const vkas_conv_geom* g, int Np, long lddy) {
 }
 bool vkas_tn_slab_n112(int Np) { return vkas_cdiv(Np, 112) * 112 < vkas_cdiv(Np, 128) * 128; }  // 112-wide tiles pad less
 
-int vkas_gemm_nt_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* Bw, int Np, const vkas_epilogue* e,
+#endif  // VKAS_MFMA_F16
+
+int VKAS_MFMA_FN(vkas_gemm_nt_mfma)(const void* x, const vkas_conv_geom* g, const void* Bw, int Np, const vkas_epilogue* e,
                            hipStream_t st) {
   const long M = (long)g->B * g->Hout * g->Wout;
   const int K = g->KH * g->KW * g->Cp;
@@ -1271,8 +1309,8 @@ int vkas_gemm_nt_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* B
     const bool head = e->mode == VKAS_EPI_HEAD;
     const long ntn = head ? e->head.n_heads : vkas_cdiv(Np, bn);
     dim3 grid((unsigned)((M / 256) * ntn));
-    const bf16_t* xp = (const bf16_t*)x;
-    const bf16_t* bp = (const bf16_t*)Bw;
+    const elem_t* xp = (const elem_t*)x;
+    const elem_t* bp = (const elem_t*)Bw;
 #define VKAS_SLAB(TNV)                                                                                                  \
   if (head) conv3x3_slab_mfma_kernel<TNV, true><<<grid, 512, 0, st>>>(xp, *g, bp, Np, M, K, *e, (unsigned)a_bytes, (unsigned)b_bytes); \
   else conv3x3_slab_mfma_kernel<TNV, false><<<grid, 512, 0, st>>>(xp, *g, bp, Np, M, K, *e, (unsigned)a_bytes, (unsigned)b_bytes);
@@ -1326,14 +1364,15 @@ static void launch_tn(const void* x, const vkas_conv_geom* g, const void* dy, lo
   const long dy_bytes = ((M - 1) * lddy + Np) * 2;
   static const bool no_buf = getenv("VKAS_TN_NOBUF") != nullptr;
   if (!no_buf && x_bytes < 0xFFFFFFF0L && dy_bytes < 0xFFFFFFF0L)
-    gemm_tn_mfma_kernel<WN, WK, TNn, TK, true, XG><<<grid, WN * WK * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy, Np,
+    gemm_tn_mfma_kernel<WN, WK, TNn, TK, true, XG><<<grid, WN * WK * 64, 0, st>>>((const elem_t*)x, *g, (const elem_t*)dy, lddy, Np,
                                                                              M, K, rows, gw, gb, (unsigned)x_bytes,
                                                                              (unsigned)dy_bytes);
   else
-    gemm_tn_mfma_kernel<WN, WK, TNn, TK, false, XG><<<grid, WN * WK * 64, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy,
+    gemm_tn_mfma_kernel<WN, WK, TNn, TK, false, XG><<<grid, WN * WK * 64, 0, st>>>((const elem_t*)x, *g, (const elem_t*)dy, lddy,
                                                                               Np, M, K, rows, gw, gb, 0u, 0u);
 }
 
+#ifndef VKAS_MFMA_F16
 // Tile choice of the TN (wgrad) kernel: N extent 128 (4 waves, 128 K columns) or 192 / 224 (8 waves, 256 K columns):
 // 8-wave tiles when there is enough work and K is wide enough; N extent = least zero padding.
 int vkas_gemm_tn_tile_choice(long M, int Np, int K) {
@@ -1354,7 +1393,9 @@ int vkas_gemm_tn_tile_choice(long M, int Np, int K) {
   return bn;
 }
 
-int vkas_gemm_tn_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
+#endif  // VKAS_MFMA_F16
+
+int VKAS_MFMA_FN(vkas_gemm_tn_mfma)(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
                            float* gb, int x_gelu, hipStream_t st) {
   const long M = (long)g->B * g->Hout * g->Wout;
   const int K = g->KH * g->KW * g->Cp;
@@ -1376,11 +1417,11 @@ int vkas_gemm_tn_mfma_bf16(const void* x, const vkas_conv_geom* g, const void* d
     const long cps = vkas_cdiv(chunks, splits);
     splits = vkas_cdiv(chunks, cps);
     if (n112)
-      conv3x3_wgrad_slab_kernel<7><<<(unsigned)(tiles * splits), 512, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy, Np, M,
+      conv3x3_wgrad_slab_kernel<7><<<(unsigned)(tiles * splits), 512, 0, st>>>((const elem_t*)x, *g, (const elem_t*)dy, lddy, Np, M,
                                                                                K, (int)cps, gw, gb, (unsigned)x_bytes,
                                                                                (unsigned)dy_bytes);
     else
-      conv3x3_wgrad_slab_kernel<8><<<(unsigned)(tiles * splits), 512, 0, st>>>((const bf16_t*)x, *g, (const bf16_t*)dy, lddy, Np, M,
+      conv3x3_wgrad_slab_kernel<8><<<(unsigned)(tiles * splits), 512, 0, st>>>((const elem_t*)x, *g, (const elem_t*)dy, lddy, Np, M,
                                                                                K, (int)cps, gw, gb, (unsigned)x_bytes,
                                                                                (unsigned)dy_bytes);
     VKAS_LAUNCH_CHECK("conv3x3_wgrad_slab");

@@ -114,9 +114,13 @@ struct ChainArgs {
 
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { typedef bf16x8 v8; typedef bf16x4 v4; };
+template <> struct Frag<f16_t> { typedef f16x8 v8; typedef f16x4 v4; };
 
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
 template <typename T, int KS, int TM, int MODE, int MINB>
@@ -303,7 +307,8 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
         }
       }
     }
-    const bool flush_now = par == 1 || !more;
+    // (forward without a destination for h = inference: nothing is kept for a backward pass)
+    const bool flush_now = (par == 1 || !more) && (MODE == MODE_BWD || p.mid_out != nullptr);
     if (flush_now) {
       flush_pair(j >> 1, par == 1 ? 64 : 32);
       if constexpr (MODE == MODE_BWD) {
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
         const v8 zq = *reinterpret_cast<const v8*>(ep + r * PE + piece * 8);
         if constexpr (MODE == MODE_FWD) {
           // z is stored in the activation type and the residual uses the rounded value (as the two-kernel path does)
-          *reinterpret_cast<v8*>(reinterpret_cast<T*>(p.z) + m * p.ldz + piece * 8) = zq;
+          if (p.z) *reinterpret_cast<v8*>(reinterpret_cast<T*>(p.z) + m * p.ldz + piece * 8) = zq;
           const float rs = p.rowscale ? p.rowscale[img] : 1.0f;
           float xr[8];
           load8(reinterpret_cast<const T*>(p.res) + m * p.ldres + piece * 8, xr);
@@ -446,10 +451,14 @@ extern "C" int vkas_mlp_chain_pack(const float* w1, const float* w2, const float
   const int ks = chain_ks(C);
   VKAS_CHECK(ks > 0, "vkas_mlp_chain_pack: C=%d is not covered (multiple of 8, <= 256)", C);
   VKAS_CHECK(mode == 0 || mode == 1, "vkas_mlp_chain_pack: mode must be 0 (forward) or 1 (backward)");
-  VKAS_CHECK(dtype == VKAS_BF16, "vkas_mlp_chain_pack: bf16 only");
+  VKAS_CHECK(dtype == VKAS_BF16 || dtype == VKAS_F16, "vkas_mlp_chain_pack: 16-bit storage types only");
   const long pieces = (long)(4 * C / 32) * (chain_img_elems(ks) / 8);
-  mlp_chain_pack_kernel<bf16_t><<<(unsigned)vkas_cdiv(pieces, 256), 256, 0, vkas_stream(stream)>>>(w1, w2, b1, C, 4 * C, ks,
-                                                                                                   mode, (bf16_t*)img);
+  if (dtype == VKAS_BF16)
+    mlp_chain_pack_kernel<bf16_t><<<(unsigned)vkas_cdiv(pieces, 256), 256, 0, vkas_stream(stream)>>>(w1, w2, b1, C, 4 * C, ks,
+                                                                                                     mode, (bf16_t*)img);
+  else
+    mlp_chain_pack_kernel<f16_t><<<(unsigned)vkas_cdiv(pieces, 256), 256, 0, vkas_stream(stream)>>>(w1, w2, b1, C, 4 * C, ks,
+                                                                                                    mode, (f16_t*)img);
   VKAS_LAUNCH_CHECK("mlp_chain_pack");
   return VKAS_OK;
 }
@@ -462,21 +471,24 @@ static int chain_check_act(const char* who, const void* p, long ld, int width) {
 extern "C" int vkas_mlp_chain_fwd(const void* yn, long ldyn, const void* img, const float* b2, const void* x, long ldx, const float* colscale, const float* rowscale, int rows_per_image, void* h, long ldh,
                                   void* z, long ldz, void* out, long ldo, long M, int C, int dtype, void* stream) {
   const char* who = "vkas_mlp_chain_fwd";
-  VKAS_CHECK(dtype == VKAS_BF16, "%s: bf16 only", who);
+  VKAS_CHECK(dtype == VKAS_BF16 || dtype == VKAS_F16, "%s: 16-bit storage types only", who);
   VKAS_CHECK(chain_ks(C) > 0, "%s: C=%d is not covered (multiple of 8, <= 256)", who, C);
   VKAS_CHECK(img && b2 && colscale && vkas_aligned16(img) && vkas_aligned16(b2) && vkas_aligned16(colscale),
              "%s: null / misaligned parameter", who);
   VKAS_CHECK(M >= 0 && rows_per_image > 0, "%s: bad sizes", who);
   int rc;
-  if ((rc = chain_check_act(who, yn, ldyn, C)) || (rc = chain_check_act(who, x, ldx, C)) || (rc = chain_check_act(who, h, ldh, 4 * C)) ||
-      (rc = chain_check_act(who, z, ldz, C)) || (rc = chain_check_act(who, out, ldo, C)))
+  if ((rc = chain_check_act(who, yn, ldyn, C)) || (rc = chain_check_act(who, x, ldx, C)) || (rc = chain_check_act(who, out, ldo, C)))
     return rc;
+  // h and z exist for the backward pass only: both NULL = inference (nothing is written for them)
+  VKAS_CHECK((h == nullptr) == (z == nullptr), "%s: h and z must be given (training) or omitted (inference) together", who);
+  if (h && ((rc = chain_check_act(who, h, ldh, 4 * C)) || (rc = chain_check_act(who, z, ldz, C)))) return rc;
   if (M == 0) return VKAS_OK;
   ChainArgs a = {};
   a.a = yn; a.lda = ldyn; a.img = img; a.mid_out = h; a.ldm = ldh; a.bias_b = b2; a.res = x; a.ldres = ldx;
   a.colscale = colscale; a.rowscale = rowscale; a.rows_per_image = rows_per_image; a.z = z; a.ldz = ldz; a.out = out; a.ldo = ldo;
   a.M = M; a.C = C; a.HID = 4 * C;
-  rc = launch_chain<bf16_t, MODE_FWD>(a, vkas_stream(stream));
+  rc = dtype == VKAS_BF16 ? launch_chain<bf16_t, MODE_FWD>(a, vkas_stream(stream))
+                          : launch_chain<f16_t, MODE_FWD>(a, vkas_stream(stream));
   if (rc) return rc;
   VKAS_LAUNCH_CHECK("mlp_chain_fwd");
   return VKAS_OK;
@@ -485,7 +497,7 @@ extern "C" int vkas_mlp_chain_fwd(const void* yn, long ldyn, const void* img, co
 extern "C" int vkas_mlp_chain_bwd(const void* dz, long lddz, const void* img_t, const void* h, long ldh, void* dh, long lddh,
                                   void* dyn, long lddyn, long M, int C, int dtype, void* stream) {
   const char* who = "vkas_mlp_chain_bwd";
-  VKAS_CHECK(dtype == VKAS_BF16, "%s: bf16 only", who);
+  VKAS_CHECK(dtype == VKAS_BF16 || dtype == VKAS_F16, "%s: 16-bit storage types only", who);
   VKAS_CHECK(chain_ks(C) > 0, "%s: C=%d is not covered (multiple of 8, <= 256)", who, C);
   VKAS_CHECK(img_t && vkas_aligned16(img_t) && M >= 0, "%s: bad arguments", who);
   int rc;
@@ -496,7 +508,8 @@ extern "C" int vkas_mlp_chain_bwd(const void* dz, long lddz, const void* img_t, 
   ChainArgs a = {};
   a.a = dz; a.lda = lddz; a.img = img_t; a.mid_out = dh; a.ldm = lddh; a.mid_in = h; a.ldmi = ldh; a.out = dyn; a.ldo = lddyn;
   a.M = M; a.C = C; a.HID = 4 * C;
-  rc = launch_chain<bf16_t, MODE_BWD>(a, vkas_stream(stream));
+  rc = dtype == VKAS_BF16 ? launch_chain<bf16_t, MODE_BWD>(a, vkas_stream(stream))
+                          : launch_chain<f16_t, MODE_BWD>(a, vkas_stream(stream));
   if (rc) return rc;
   VKAS_LAUNCH_CHECK("mlp_chain_bwd");
   return VKAS_OK;

@@ -55,12 +55,27 @@ __global__ void pad_vector_kernel(const float* __restrict__ v, float* __restrict
   if (i < np) out[i] = i < n ? v[i] : 0.f;
 }
 
+// out = [49][Cp] taps x channels, followed by the channel-pair rows the planar bf16 kernel reads with ONE scalar load per
+// kernel row: [Cp / 2 pairs][7 ky][16] = (w[ky][kx][2p], w[ky][kx][2p + 1]) for kx = 0..6, two pad floats
 __global__ void pack_dw_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int C, int Cp, int flip) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 49*Cp
-  if (i >= 49 * Cp) return;
-  const int tap = i / Cp, c = i - tap * Cp;
-  const int src_tap = flip ? 48 - tap : tap;
-  out[i] = c < C ? w[(long)c * 49 + src_tap] : 0.f;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 49*Cp + (Cp/2)*7*16
+  if (i < 49 * Cp) {
+    const int tap = i / Cp, c = i - tap * Cp;
+    const int src_tap = flip ? 48 - tap : tap;
+    out[i] = c < C ? w[(long)c * 49 + src_tap] : 0.f;
+    return;
+  }
+  const int j = i - 49 * Cp;
+  if (j >= (Cp / 2) * 112) return;
+  const int p = j / 112, r = j - p * 112;
+  const int ky = r >> 4, e = r & 15;
+  const int kx = e >> 1, c = 2 * p + (e & 1);
+  float v = 0.f;
+  if (kx < 7 && c < C) {
+    const int tap = ky * 7 + kx;
+    v = w[(long)c * 49 + (flip ? 48 - tap : tap)];
+  }
+  out[i] = v;
 }
 
 __global__ void unpack_dw_wgrad_kernel(const float* __restrict__ gw, float* __restrict__ grad, int C, int Cp,
@@ -204,9 +219,11 @@ extern "C" int vkas_pad_vector(const float* v, float* out, int n, int np, void* 
   return VKAS_OK;
 }
 
+extern "C" size_t vkas_dw_weight_elems(int Cp) { return (size_t)105 * (size_t)Cp; }  // 49 Cp + (Cp / 2) * 7 * 16
+
 extern "C" int vkas_pack_dw_weight(const float* w, float* out, int C, int Cp, int flip, void* stream) {
   VKAS_CHECK(w && out && C > 0 && Cp >= C && Cp % 8 == 0, "vkas_pack_dw_weight: bad arguments");
-  pack_dw_weight_kernel<<<(unsigned)vkas_cdiv(49L * Cp, 256), 256, 0, vkas_stream(stream)>>>(w, out, C, Cp, flip);
+  pack_dw_weight_kernel<<<(unsigned)vkas_cdiv(105L * Cp, 256), 256, 0, vkas_stream(stream)>>>(w, out, C, Cp, flip);
   VKAS_LAUNCH_CHECK("pack_dw_weight");
   return VKAS_OK;
 }

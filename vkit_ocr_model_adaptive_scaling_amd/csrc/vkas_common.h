@@ -11,6 +11,9 @@
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -41,6 +44,9 @@ void vkas_set_error(const char* fmt, ...);
   } else if ((dtype) == VKAS_BF16) {                           \
     using T = bf16_t;                                          \
     __VA_ARGS__                                                \
+  } else if ((dtype) == VKAS_F16) {                            \
+    using T = f16_t;                                           \
+    __VA_ARGS__                                                \
   } else {                                                     \
     vkas_set_error("%s: unknown dtype %d", NAME, (int)(dtype)); \
     return VKAS_E_ARG;                                         \
@@ -53,9 +59,11 @@ static inline long vkas_cdiv(long a, long b) { return (a + b - 1) / b; }
 // ---- device helpers -------------------------------------------------------------------------------
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }
 
 // 8 consecutive elements <-> 8 floats.  Pointers must be 16-byte aligned (8-element granularity).
 __device__ __forceinline__ void load8(const float* p, float* v) {
@@ -65,6 +73,11 @@ __device__ __forceinline__ void load8(const float* p, float* v) {
 }
 __device__ __forceinline__ void load8(const bf16_t* p, float* v) {
   const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+__device__ __forceinline__ void load8(const f16_t* p, float* v) {
+  const f16x8 a = *reinterpret_cast<const f16x8*>(p);
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
 }
@@ -78,6 +91,12 @@ __device__ __forceinline__ void store8(bf16_t* p, const float* v) {
   for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
   *reinterpret_cast<bf16x8*>(p) = a;
 }
+__device__ __forceinline__ void store8(f16_t* p, const float* v) {
+  f16x8 a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = (f16_t)v[i];
+  *reinterpret_cast<f16x8*>(p) = a;
+}
 __device__ __forceinline__ void load4(const float* p, float* v) {
   const float4 a = *reinterpret_cast<const float4*>(p);
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
@@ -86,6 +105,17 @@ __device__ __forceinline__ void load4(const bf16_t* p, float* v) {
   const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
 #pragma unroll
   for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
+}
+__device__ __forceinline__ void load4(const f16_t* p, float* v) {
+  const f16x4 a = *reinterpret_cast<const f16x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
+}
+__device__ __forceinline__ void store4(f16_t* p, const float* v) {
+  f16x4 a;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = (f16_t)v[i];
+  *reinterpret_cast<f16x4*>(p) = a;
 }
 __device__ __forceinline__ void store4(float* p, const float* v) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -134,6 +164,7 @@ template <> __device__ __forceinline__ float gelu_t<bf16_t>(float x) {
   gelu_parts_fast(x, cdf, pdf);
   return fmaxf(x, -4.25f) * cdf;
 }
+template <> __device__ __forceinline__ float gelu_t<f16_t>(float x) { return gelu_t<bf16_t>(x); }
 template <typename T> __device__ __forceinline__ float dgelu_t(float x);
 template <> __device__ __forceinline__ float dgelu_t<float>(float x) { return dgelu_f(x); }
 // gelu'(x) = Phi(x) + x phi(x) = 0.5 + x * Q(x^2) on |x| <= 4.5 (degree 9, |error| <= 1.8e-4 of a value in [−0.13, 1.13];
@@ -164,3 +195,4 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+template <> __device__ __forceinline__ float dgelu_t<f16_t>(float x) { return dgelu_t<bf16_t>(x); }

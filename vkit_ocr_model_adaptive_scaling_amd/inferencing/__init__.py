@@ -1,0 +1,7 @@
+from .opt import pad_length_to_make_divisible, pad_mat_to_make_divisible
+from .adaptive_scaling import (
+    AdaptiveScalingInferencingConfig,
+    AdaptiveScalingInferencingRoughInferResult,
+    AdaptiveScalingInferencingPresiceInferResult,
+    AdaptiveScalingInferencing,
+)

@@ -1,0 +1,181 @@
+"""Tensor side of the adaptive-scaling inference path (mirror of vkit_open_model/inferencing/adaptive_scaling.py:92-188,
+295-396 and the shape rules of :95-107): pad-to-32, the short-side-720 rule, the no-grad model calls and the
+sigmoid / threshold / softmax / padding-mask post-processing, which runs on the device (csrc/infer.hip).
+
+Out of scope: the CPU geometry around it - polygons from masks, text-region flattening / stacking,
+polygon building (vkit, cv2, scipy; third-party code that is absent here).  Images are plain (H, W, 3) uint8 arrays
+instead of ``vkit.element.Image``; results carry numpy arrays instead of ``Mask`` / ``ScoreMap``.  The reference loads
+a TorchScript file (``model_jit``); this mirror takes the ``AdaptiveScaling`` module (or a state-dict file in the
+reference's schema) since its ops are ``autograd.Function``s, not scriptable.
+"""
+import ctypes
+import math
+from typing import Optional, Sequence, Tuple, Union
+
+import attrs
+import numpy as np
+import torch
+
+from .opt import pad_mat_to_make_divisible
+from .. import ops
+from .._lib import lib, check
+from ..model import AdaptiveScaling, AdaptiveScalingConfig
+
+
+@attrs.define
+class AdaptiveScalingInferencingConfig:
+    """inferencing/adaptive_scaling.py:41-58 (tensor-side fields, same names - including the reference's spelling
+    ``legnth`` - and defaults).  ``model_jit`` may be an ``AdaptiveScaling`` module or the path of a state-dict file."""
+    model_jit: Union[str, AdaptiveScaling, None] = None
+    device: str = 'cuda'
+    backbone_downsampling_factor: int = 32
+    rough_head_upsampling_factor: int = 2
+    rough_downsample_short_side_legnth: int = 720
+    rough_char_mask_positive_thr: float = 0.5
+    rough_valid_char_height_min: float = 3.0
+    precise_head_upsampling_factor: int = 2
+    precise_char_mask_positive_thr: float = 0.5
+    model_config: Optional[AdaptiveScalingConfig] = None  # needed to rebuild the module from a state-dict file
+    compute_dtype: torch.dtype = torch.float16            # BASELINE.json configs[4]
+
+
+@attrs.define
+class AdaptiveScalingInferencingRoughInferResult:
+    """:61-66"""
+    resized_shape: Tuple[int, int]
+    padded_image: np.ndarray
+    rough_char_mask: np.ndarray              # (H/FDF, W/FDF) uint8
+    rough_char_height_score_map: np.ndarray  # (H/FDF, W/FDF) float32
+
+
+@attrs.define
+class AdaptiveScalingInferencingPresiceInferResult:
+    """:69-76 (the reference's spelling)"""
+    padded_image: np.ndarray
+    precise_char_mask: Optional[np.ndarray]
+    precise_char_prob_score_map: np.ndarray
+    precise_np_char_up_left_corner_offset: np.ndarray      # (H/FDF, W/FDF, 2)
+    precise_np_char_corner_angle_distribution: np.ndarray  # (H/FDF, W/FDF, 4)
+    precise_np_char_corner_distance: np.ndarray            # (H/FDF, W/FDF, 4)
+
+
+def rough_resized_shape(height: int, width: int, short_side: int) -> Tuple[int, int]:
+    """:95-107: when the shorter side exceeds ``short_side`` the image is shrunk so that it equals it (the other side
+    keeps the aspect ratio, rounded like vkit's ``to_resized_image``)."""
+    if min(height, width) <= short_side:
+        return height, width
+    if height < width:
+        return short_side, round(short_side * width / height)
+    return round(short_side * height / width), short_side
+
+
+def _as_mat(image) -> np.ndarray:
+    mat = getattr(image, 'mat', image)
+    mat = np.asarray(mat)
+    if mat.ndim != 3 or mat.shape[2] != 3:
+        raise ValueError(f'expected an (H, W, 3) RGB image, got {mat.shape}')
+    return mat
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class AdaptiveScalingInferencing:
+    """:79-188,295-396 without the vkit geometry."""
+
+    def __init__(self, config: AdaptiveScalingInferencingConfig):
+        self.config = config
+        model = config.model_jit
+        if isinstance(model, str):
+            if config.model_config is None:
+                raise ValueError('model_config is required to rebuild the module from a state-dict file')
+            sd = torch.load(model, map_location='cpu', weights_only=True)
+            sd = sd.get('model_jit_state_dict', sd) if isinstance(sd, dict) else sd  # RestoreState schema, train.py:91-96
+            module = AdaptiveScaling(config.model_config)
+            module.load_state_dict(sd)
+            model = module
+        if not isinstance(model, AdaptiveScaling):
+            raise TypeError('config.model_jit must be an AdaptiveScaling module or the path of its state dict')
+        self.model = model.to(config.device).eval()
+        self.model.set_compute_dtype(config.compute_dtype)
+
+    # ---- shared pieces ------------------------------------------------------------------------------------------
+    def _to_device(self, mats: Sequence[np.ndarray]) -> torch.Tensor:
+        """(H, W, 3) uint8 arrays of one padded size -> (B, 3, H, W) fp32 on the device (:117-122)."""
+        x = torch.from_numpy(np.stack([np.ascontiguousarray(m) for m in mats]))
+        x = x.to(self.config.device, non_blocking=True)
+        return x.permute(0, 3, 1, 2).float()
+
+    @staticmethod
+    def _valid(sizes: Sequence[Tuple[int, int]], fdf: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+        vh = torch.tensor([math.ceil(h / fdf) for h, _ in sizes], dtype=torch.int32, device=device)
+        vw = torch.tensor([math.ceil(w / fdf) for _, w in sizes], dtype=torch.int32, device=device)
+        return vh, vw
+
+    # ---- rough pass ----------------------------------------------------------------------------------------------
+    def rough_infer(self, image, resize_fn=None) -> AdaptiveScalingInferencingRoughInferResult:
+        """:92-188.  ``resize_fn(mat, height, width)`` performs the area-interpolation shrink of the 720 rule (cv2 in the
+        reference); without it an image that needs shrinking is rejected - resampling pixels is host-side image I/O."""
+        c = self.config
+        mat = _as_mat(image)
+        h, w = rough_resized_shape(mat.shape[0], mat.shape[1], c.rough_downsample_short_side_legnth)
+        if (h, w) != mat.shape[:2]:
+            if resize_fn is None:
+                raise ValueError(f'image {mat.shape[:2]} exceeds the short-side limit {c.rough_downsample_short_side_legnth}: '
+                                 f'pass resize_fn or an image already resized to {(h, w)}')
+            mat = np.asarray(resize_fn(mat, h, w))
+            assert mat.shape[:2] == (h, w)
+        padded = pad_mat_to_make_divisible(mat, c.backbone_downsampling_factor)
+        fdf = 4 // c.rough_head_upsampling_factor
+        x = self._to_device([padded])
+        with torch.no_grad():
+            mask_feat, height_feat = self.model.forward_rough(x)
+        B, _, H, W = mask_feat.shape
+        assert (H, W) == (padded.shape[0] // fdf, padded.shape[1] // fdf) and height_feat.shape == mask_feat.shape
+        vh, vw = self._valid([(h, w)], fdf, x.device)
+        out_mask = torch.empty((B, H, W), dtype=torch.uint8, device=x.device)
+        out_height = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
+        check(lib.vkas_rough_postprocess(_ptr(mask_feat.contiguous()), _ptr(height_feat.contiguous()), B, H, W, _ptr(vh), _ptr(vw),
+                                         float(c.rough_char_mask_positive_thr), float(c.rough_valid_char_height_min),
+                                         _ptr(out_mask), _ptr(out_height), ops._stream()), 'rough_postprocess')
+        return AdaptiveScalingInferencingRoughInferResult(
+            resized_shape=(math.ceil(h / fdf), math.ceil(w / fdf)), padded_image=padded,
+            rough_char_mask=out_mask[0].cpu().numpy(), rough_char_height_score_map=out_height[0].cpu().numpy())
+
+    # ---- precise pass --------------------------------------------------------------------------------------------
+    def precise_infer_batch(self, images: Sequence) -> Sequence[AdaptiveScalingInferencingPresiceInferResult]:
+        """:295-396 for a batch of stacked-region pages: each is padded to x32, pages of one padded size share a model
+        call (the reference feeds one page at a time)."""
+        c = self.config
+        mats = [_as_mat(im) for im in images]
+        padded = [pad_mat_to_make_divisible(m, c.backbone_downsampling_factor) for m in mats]
+        fdf = 4 // c.precise_head_upsampling_factor
+        results = [None] * len(mats)
+        groups = {}
+        for i, p in enumerate(padded):
+            groups.setdefault(p.shape[:2], []).append(i)
+        for shape, idxs in groups.items():
+            x = self._to_device([padded[i] for i in idxs])
+            with torch.no_grad():
+                prob, offset, angle, dist = self.model.forward_precise(x)
+            B, _, H, W = prob.shape
+            assert (H, W) == (shape[0] // fdf, shape[1] // fdf)
+            vh, vw = self._valid([mats[i].shape[:2] for i in idxs], fdf, x.device)
+            o_prob = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
+            o_off = torch.empty((B, H, W, 2), dtype=torch.float32, device=x.device)
+            o_ang = torch.empty((B, H, W, 4), dtype=torch.float32, device=x.device)
+            o_dist = torch.empty((B, H, W, 4), dtype=torch.float32, device=x.device)
+            check(lib.vkas_precise_postprocess(_ptr(prob.contiguous()), _ptr(offset.contiguous()), _ptr(angle.contiguous()),
+                                               _ptr(dist.contiguous()), B, H, W, _ptr(vh), _ptr(vw), _ptr(o_prob), _ptr(o_off),
+                                               _ptr(o_ang), _ptr(o_dist), ops._stream()), 'precise_postprocess')
+            o_prob, o_off, o_ang, o_dist = (t.cpu().numpy() for t in (o_prob, o_off, o_ang, o_dist))
+            for k, i in enumerate(idxs):
+                results[i] = AdaptiveScalingInferencingPresiceInferResult(
+                    padded_image=padded[i], precise_char_mask=None, precise_char_prob_score_map=o_prob[k],
+                    precise_np_char_up_left_corner_offset=o_off[k], precise_np_char_corner_angle_distribution=o_ang[k],
+                    precise_np_char_corner_distance=o_dist[k])
+        return results
+
+    def precise_infer(self, image) -> AdaptiveScalingInferencingPresiceInferResult:
+        return self.precise_infer_batch([image])[0]

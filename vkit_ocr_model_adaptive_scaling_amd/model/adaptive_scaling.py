@@ -106,7 +106,7 @@ class AdaptiveScaling(nn.Module):
             for cv, nm, proj in zip(convs, norms, projs):
                 fused.extend([cv.weight, cv.bias, nm.weight, nm.bias, proj.weight, proj.bias])
             outs = []
-            for h, hp, y in zip(heads, plain, ops.HeadsFused.apply(up, *fused)):
+            for h, hp, y in zip(heads, plain, ops.HeadsFused.apply(up, torch.is_grad_enabled(), *fused)):
                 y = ops.ToNchw.apply(y, hp.out_channels)
                 outs.append(h[1](y) if isinstance(h, nn.Sequential) else y)
             return tuple(outs)

@@ -46,7 +46,7 @@ class ConvNextBlockLayer(nn.Module):
             mask = self.stochastic_depth_mask(x.shape[0], x.device)
         dw, norm, fc1, fc2 = self.block[0], self.block[2], self.block[3], self.block[5]
         return ops.ConvNextLayer.apply(x, dw.weight, dw.bias, norm.weight, norm.bias, fc1.weight, fc1.bias,
-                                       fc2.weight, fc2.bias, self.block_scale, mask)
+                                       fc2.weight, fc2.bias, self.block_scale, mask, torch.is_grad_enabled())
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # type: ignore
         c = x.shape[1]

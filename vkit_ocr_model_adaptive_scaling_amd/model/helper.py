@@ -122,9 +122,10 @@ def conv_block(x, conv: nn.Module, norm: nn.LayerNorm, stride: int = 1, pad: int
 
 def set_compute_dtype(module: nn.Module, dtype: torch.dtype) -> nn.Module:
     """Select the activation storage type of every module of this package below ``module``:
-    torch.bfloat16 (MFMA path, default) or torch.float32 (exact-fp32 parity mode)."""
-    if dtype not in (torch.bfloat16, torch.float32):
-        raise ValueError('compute dtype must be torch.bfloat16 or torch.float32')
+    torch.bfloat16 (MFMA path, default), torch.float16 (MFMA path; the reference's fp16 inference, BASELINE.json
+    configs[4]) or torch.float32 (exact-fp32 parity mode)."""
+    if dtype not in (torch.bfloat16, torch.float16, torch.float32):
+        raise ValueError('compute dtype must be torch.bfloat16, torch.float16 or torch.float32')
     for m in module.modules():
         if hasattr(m, 'compute_dtype'):
             m.compute_dtype = dtype

@@ -25,12 +25,19 @@ def rup8(c: int) -> int:
     return (c + 7) // 8 * 8
 
 
+_DTYPE_CODES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
+_MFMA_DTYPES = (torch.bfloat16, torch.float16)  # 16-bit storage types with MFMA kernels (fp32 accumulate)
+
+
+def _dtc(dtype: torch.dtype) -> int:
+    try:
+        return _DTYPE_CODES[dtype]
+    except KeyError:
+        raise TypeError(f'unsupported activation dtype {dtype}') from None
+
+
 def _dt(t: torch.Tensor) -> int:
-    if t.dtype == torch.bfloat16:
-        return _lib.BF16
-    if t.dtype == torch.float32:
-        return _lib.F32
-    raise TypeError(f'unsupported activation dtype {t.dtype}')
+    return _dtc(t.dtype)
 
 
 def _stream():
@@ -124,7 +131,7 @@ def pack_conv_weight(w: torch.Tensor, Np: int, Cp: int, mode: int, dtype: torch.
         N, C, KH, KW = w4.shape
         out = torch.empty((Np * KH * KW * Cp,), dtype=dtype, device=w.device)
         check(lib.vkas_pack_conv_weight(_p(w4.contiguous()), _p(out), N, C, KH, KW, Np, Cp, mode,
-                                        _lib.BF16 if dtype == torch.bfloat16 else _lib.F32, _stream()), 'pack_conv_weight')
+                                        _dtc(dtype), _stream()), 'pack_conv_weight')
         return out
     return _cached_pack(w, ('conv', Np, Cp, mode, dtype), build)
 
@@ -148,7 +155,7 @@ _NO_CHAIN = os.environ.get('VKAS_NO_MLP_CHAIN') is not None  # A/B switch: force
 
 def mlp_chain_eligible(x: torch.Tensor, C: int) -> bool:
     """The fused ConvNeXt MLP kernels (csrc/mlp_chain.hip) cover bf16 activations with C % 8 == 0, C <= 256."""
-    return (not _NO_CHAIN and x.dtype == torch.bfloat16 and x.shape[3] == C
+    return (not _NO_CHAIN and x.dtype in _MFMA_DTYPES and x.shape[3] == C
             and lib.vkas_mlp_chain_image_elems(C) > 0)
 
 
@@ -158,7 +165,7 @@ def pack_mlp_chain(w1: torch.Tensor, w2: torch.Tensor, b1: Optional[torch.Tensor
     def build():
         img = torch.empty((lib.vkas_mlp_chain_image_elems(C),), dtype=dtype, device=w1.device)
         check(lib.vkas_mlp_chain_pack(_p(w1.contiguous()), _p(w2.contiguous()), _p(b1.contiguous()) if mode == 0 else None, C,
-                                      mode, _p(img), _lib.BF16, _stream()), 'mlp_chain_pack')
+                                      mode, _p(img), _dtc(dtype), _stream()), 'mlp_chain_pack')
         return img
     if mode == 0:  # the forward image also depends on b1: key on (w1, w2) and stamp b1's version into the key
         return _cached_pack_pair(w1, w2, ('chain', C, mode, dtype, b1._version, b1.data_ptr()), build)
@@ -167,7 +174,7 @@ def pack_mlp_chain(w1: torch.Tensor, w2: torch.Tensor, b1: Optional[torch.Tensor
 
 def pack_dw_weight(w: torch.Tensor, C: int, Cp: int, flip: int) -> torch.Tensor:
     def build():
-        out = torch.empty((49 * Cp,), dtype=_FLOAT, device=w.device)
+        out = torch.empty((lib.vkas_dw_weight_elems(Cp),), dtype=_FLOAT, device=w.device)
         check(lib.vkas_pack_dw_weight(_p(w.contiguous()), _p(out), C, Cp, flip, _stream()), 'pack_dw_weight')
         return out
     return _cached_pack(w, ('dw', C, Cp, flip), build)
@@ -250,7 +257,7 @@ def conv_gemm(x: torch.Tensor, geom: ConvGeom, Bw: torch.Tensor, Np: int, out: t
         # algorithmic FLOPs use the logical (unpadded) N and K when the caller knows them
         M = geom.B * geom.Hout * geom.Wout
         N, K = nk if nk is not None else (Np, geom.KH * geom.KW * geom.Cp)
-        if x.dtype == torch.bfloat16:
+        if x.dtype in _MFMA_DTYPES:
             wmax = max(head.np[i] for i in range(head.n_heads)) if head is not None else 0
             kind = nt_kernel_name(lib.vkas_conv_gemm_kernel_id(0, ctypes.byref(geom), Np, 0, wmax), head is not None)
         else:
@@ -266,7 +273,8 @@ def conv_gemm(x: torch.Tensor, geom: ConvGeom, Bw: torch.Tensor, Np: int, out: t
 
 def _conv_gemm(x, geom, Bw, Np, out, mode, bias, out2, aux, colscale, rowscale, rows_per_image, patch, patch_hw,
                patch_Cp, head=None):
-    epi = Epilogue(mode, _p(bias).value if bias is not None else None, out.data_ptr(), act_ld(out),
+    epi = Epilogue(mode, _p(bias).value if bias is not None else None, out.data_ptr() if out is not None else None,
+                   act_ld(out) if out is not None else 0,
                    out2.data_ptr() if out2 is not None else None, act_ld(out2) if out2 is not None else 0,
                    aux.data_ptr() if aux is not None else None, act_ld(aux) if aux is not None else 0,
                    colscale.data_ptr() if colscale is not None else None,
@@ -330,7 +338,7 @@ def conv_wgrad(x: torch.Tensor, geom: ConvGeom, dy: torch.Tensor, Np: int, nk=No
         fn = lib.vkas_conv_gemm_wgrad_gelu if x_gelu else lib.vkas_conv_gemm_wgrad
         check(fn(_p(x), ctypes.byref(geom), _p(dy), act_ld(dy), Np, _p(gw), _p(gb), _dt(x), _stream()), 'conv_gemm_wgrad')
         return (gw, gb) if with_bias else gw
-    if x.dtype == torch.bfloat16:
+    if x.dtype in _MFMA_DTYPES:
         kid = lib.vkas_conv_gemm_kernel_id(1, ctypes.byref(geom), Np, act_ld(dy), 0)
         if x_gelu and kid >= 2000:  # the gelu-on-load variant exists for the generic kernel only
             kid = lib.vkas_conv_gemm_tile(1, M, Np, K)
@@ -461,7 +469,7 @@ class ImageToAct(Function):
         B, C, H, W = img.shape
         out = torch.empty((B, H, W, 8), dtype=dtype, device=img.device)
         check(lib.vkas_image_nchw_to_nhwc8(_p(img), _p(out), B, C, H, W,
-                                           _lib.BF16 if dtype == torch.bfloat16 else _lib.F32, _stream()),
+                                           _dtc(dtype), _stream()),
               'image_nchw_to_nhwc8')
         ctx.mark_non_differentiable(out)
         return out
@@ -633,7 +641,7 @@ def pack_head_weights(ws: Sequence[torch.Tensor], nps: Sequence[int], Cp: int, m
         for w, np_ in zip(ws, nps):
             N, C = w.shape[0], w.shape[1]
             check(lib.vkas_pack_conv_weight_slice(_p(w.contiguous()), _p(out), N, C, KH, KW, np_, Cp, mode, off, Nt,
-                                                  _lib.BF16 if dtype == torch.bfloat16 else _lib.F32, _stream()),
+                                                  _dtc(dtype), _stream()),
                   'pack_conv_weight_slice')
             off += np_
         return out
@@ -654,11 +662,12 @@ class HeadsFused(Function):
     @staticmethod
     def eligible(x, channels, out_channels) -> bool:
         M = x.shape[0] * x.shape[1] * x.shape[2]
-        return (x.dtype == torch.bfloat16 and M >= 16384 and len(channels) <= 4 and max(rup8(c) for c in channels) <= 224
+        return (x.dtype in _MFMA_DTYPES and M >= 16384 and len(channels) <= 4 and max(rup8(c) for c in channels) <= 224
                 and max(out_channels) <= 4)
 
     @staticmethod
-    def forward(ctx, x, *params):
+    def forward(ctx, x, keep: bool, *params):
+        """keep: torch.is_grad_enabled() at the call site (Function.forward itself always runs with grad mode off)."""
         _require_cuda(x, params[0])
         x = as_act(x)
         n_heads = len(params) // 6
@@ -693,8 +702,9 @@ class HeadsFused(Function):
             return t
         hp = _cached_pack_multi(list(gammas) + list(betas) + list(wps) + list(bps), ('head_params', pw), build_hp)
         b_cat = _cached_pack_multi(list(bs), ('head_bias', tuple(nps)), build_bias)
-        z = new_act(B, H, W, Nt, x)
-        stats = torch.empty((n_heads, M, 2), dtype=_FLOAT, device=dev)
+        # z and the row statistics only serve the backward pass: an inference (no-grad) call does not write them
+        z = new_act(B, H, W, Nt, x) if keep else None
+        stats = torch.empty((n_heads, M, 2), dtype=_FLOAT, device=dev) if keep else None
         proj = torch.empty((n_heads, B, H, W, 8), dtype=_FLOAT, device=dev)
         head = _lib.HeadDesc()
         head.n_heads, head.pw = n_heads, pw
@@ -702,11 +712,12 @@ class HeadsFused(Function):
         for h in range(n_heads):
             head.n0[h], head.np[h], head.c[h], head.oc[h] = off, nps[h], cs[h], ocs[h]
             off += nps[h]
-        head.params, head.stats, head.proj = hp.data_ptr(), stats.data_ptr(), proj.data_ptr()
+        head.params, head.stats, head.proj = hp.data_ptr(), stats.data_ptr() if keep else None, proj.data_ptr()
         geom = _geom(B, H, W, H, W, Cp, act_ld(x), 3, 3, 1, 1)
         Bw = pack_head_weights(ws, nps, Cp, 0, x.dtype)
         conv_gemm(x, geom, Bw, Nt, z, _lib.EPI_HEAD, bias=b_cat, nk=(sum(cs), C * 9), head=head)
-        ctx.save_for_backward(x, z, stats, hp, *ws, *bs)
+        if keep:
+            ctx.save_for_backward(x, z, stats, hp, *ws, *bs)
         ctx.meta = (cs, ocs, nps, pw, C)
         return tuple(proj[h] for h in range(n_heads))
 
@@ -768,7 +779,7 @@ class HeadsFused(Function):
             d = dparams[h]
             grads.extend([gws[h], gbs[h], d[:cs[h]], d[pw:pw + cs[h]], d[2 * pw:6 * pw].view(4, pw)[:ocs[h], :cs[h]],
                           d[6 * pw:6 * pw + ocs[h]]])
-        return (dx, *grads)
+        return (dx, None, *grads)
 
 
 class ConvNextLayer(Function):
@@ -779,7 +790,9 @@ class ConvNextLayer(Function):
     probability (:41-53) or None."""
 
     @staticmethod
-    def forward(ctx, x, dw_w, dw_b, ln_g, ln_b, w1, b1, w2, b2, block_scale, rowscale):
+    def forward(ctx, x, dw_w, dw_b, ln_g, ln_b, w1, b1, w2, b2, block_scale, rowscale, keep: bool = True):
+        """keep: torch.is_grad_enabled() at the call site (Function.forward itself always runs with grad mode off);
+        False = inference, the backward operands h and z are not written."""
         _require_cuda(x, dw_w)
         x = as_act(x)
         B, H, W, Cp = x.shape
@@ -806,7 +819,9 @@ class ConvNextLayer(Function):
         if chain:
             # one kernel: h = yn W1^T + b1 is written once (for backward), gelu(h) goes from the first matrix product
             # into the second in registers, the layer-scale / stochastic-depth / residual epilogue follows
-            h = new_act(B, H, W, C4p, x)
+            h = new_act(B, H, W, C4p, x) if keep else None
+            if not keep:
+                z = None
             g = None
             img = pack_mlp_chain(w1, w2, b1, C, 0, x.dtype)
             es = x.element_size()
@@ -814,7 +829,9 @@ class ConvNextLayer(Function):
                    lambda: check(lib.vkas_mlp_chain_fwd(_p(yn), Cp, _p(img), _p(pad_vector(b2, Cp)),
                                                         _p(x), act_ld(x), _p(cs), _p(rs), H * W, _p(h), C4p, _p(z), Cp,
                                                         _p(out), Cp, M, C, dt, st), 'mlp_chain_fwd'),
-                   float(M) * (4 * Cp + C4p) * es)
+                   float(M) * ((4 * Cp + C4p) if keep else 3 * Cp) * es)
+            if not keep:
+                return out
         else:
             h = new_act(B, H, W, C4p, x)
             g = new_act(B, H, W, C4p, x)
@@ -901,7 +918,7 @@ class ConvNextLayer(Function):
                                                         W, Cp, dt, st), 'dwconv7x7_dgrad'), 3.0 * M * Cp * x.element_size())
         gdb_, dlg, dlb, db2_, dsc = deliver_small_grads([(dw_b, gdb[:C]), (ln_g, dlg), (ln_b, dlb), (b2, db2[:C]),
                                                          (block_scale, dscale[:C].view(block_scale.shape))])
-        return (dx, gdw_ref, gdb_, dlg, dlb, gw1, db1, gw2, db2_, dsc, None)
+        return (dx, gdw_ref, gdb_, dlg, dlb, gw1, db1, gw2, db2_, dsc, None, None)
 
 
 class Resize(Function):
@@ -1042,7 +1059,7 @@ class ToNchw(Function):
         B, C, H, W = g.shape
         out = torch.empty((B, H, W, Cp), dtype=dtype, device=g.device)
         check(lib.vkas_nchw_f32_to_nhwc(_p(g), _p(out), Cp, B, H, W, C, Cp,
-                                        _lib.BF16 if dtype == torch.bfloat16 else _lib.F32, _stream()),
+                                        _dtc(dtype), _stream()),
               'nchw_f32_to_nhwc')
         return out, None
 
