@@ -138,7 +138,7 @@ int vkas_conv_gemm_wgrad(const void* x, const vkas_conv_geom* g, const void* dy,
 int vkas_conv_gemm_wgrad_gelu(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
                               float* gb, int dtype, void* stream);
 
-/* ---- fused ConvNeXt MLP (convnext.py:33-35,54-58), C % 8 == 0, C <= 256, bf16 --------------------------------------
+/* ---- fused ConvNeXt MLP (convnext.py:33-35,54-58), C % 8 == 0, C <= 512, 16-bit storage --------------------------------------
  * Linear(C,4C) -> GELU -> Linear(4C,C) -> layer scale -> stochastic depth -> residual as one kernel per direction; the
  * (M, 4C) activation is written once (h, for backward) and never read back between the two matrix products.
  * Weights are consumed as a packed, pre-swizzled LDS image: vkas_mlp_chain_image_elems(C) elements of `dtype`, built by

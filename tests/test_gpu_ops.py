@@ -177,9 +177,10 @@ torch.save({'y': y.float().cpu(), 'gx': x.grad.float().cpu(), 'gw': w.grad.cpu()
 # --------------------------------------------------------------------------------------------- dwconv / layer
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('shape', [(2, 24, 19, 37), (1, 16, 8, 8), (2, 96, 40, 33), (1, 40, 5, 3),
-                                   # every instantiation of the fused MLP kernel (C <= 32 / 64 / 96 / 128 / 192 / 256) and one
-                                   # width beyond it (two-GEMM path)
-                                   (1, 64, 7, 9), (2, 128, 12, 9), (1, 192, 9, 7), (1, 256, 6, 5), (1, 264, 4, 4)])
+                                   # every instantiation of the fused MLP kernel (C <= 32 / 64 / 96 / 128 / 192 / 256 / 384 /
+                                   # 512) and one width beyond it (two-GEMM path)
+                                   (1, 64, 7, 9), (2, 128, 12, 9), (1, 192, 9, 7), (1, 256, 6, 5), (1, 264, 4, 4),
+                                   (2, 384, 9, 5), (1, 512, 6, 7), (1, 520, 3, 3)])
 def test_convnext_layer(shape, dtype):
     """Whole ConvNextBlockLayer (dw7x7, LN, MLP, layer scale, stochastic depth mask, residual) fwd + bwd."""
     ops = ops_mod()
@@ -215,7 +216,7 @@ def test_convnext_layer(shape, dtype):
     assert r < gtol, ('dx', r)
 
 
-@pytest.mark.parametrize('C', [16, 96, 192])
+@pytest.mark.parametrize('C', [16, 96, 192, 384])
 def test_mlp_chain_matches_two_gemm_path(C):
     """The fused MLP kernels against the two-GEMM layer path they replace (same bf16 inputs; the two differ only in
     where fp32 values are rounded to bf16): outputs and every gradient, ragged M (not a multiple of the 256/128-row tile),

@@ -351,6 +351,198 @@ __global__ __launch_bounds__(256, 2) void dwconv7x7_planar_kernel(const bf16_t* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 16-bit forward / dgrad on the MATRIX cores.  49 fp32 FMAs per output element put the VALU formulations above on the
+// vector-ALU roof (157 TFLOP/s: 63 us for a stage-0 launch before a single conversion or LDS read is issued, HBM needs
+// 73 us), so this kernel moves the arithmetic to MFMA: per channel and kernel row ky, the 7 taps along x are a banded
+// (Toeplitz) 16 x 32 matrix A_ky[i][k] = w[ky][k - i - 5] that maps 32 input positions to 16 outputs, and
+//      D[i = output x][j = image row] += A_ky[i][k] * B[k = input x][j],  B = the input of 16 image rows,
+// is one v_mfma_f32_16x16x32 (7 useful of 32 k per row: 22 % of the matrix peak = 550 TFLOP/s effective, no operand
+// conversions, fp32 accumulation).  B needs 8 consecutive x of ONE channel per lane, so the halo tile is staged channel-
+// planar ([channel][row][x], 16-bit), transposed on the way in with ds_write_b16; results leave through fp32 planes and
+// are re-assembled into 16-byte channel chunks.  The band matrices (28 registers per channel) are built once per workgroup:
+// workgroups are persistent (8 waves), own a 16-channel slice (a wave 2 channels) and walk the spatial tiles of that slice with the
+// next tile's halo prefetched into registers.
+constexpr int MTY = 16, MTX = 32, MIY = MTY + 6, MIX = MTX + 6;
+constexpr int MIP = 48;                         // elements per staged row: x0-8 .. x0+39 (16-byte aligned 8-element windows)
+constexpr int MPB_IN = 2144 / 2;                // elements per input plane (>= 22 * 48; 536 words = 24 mod 32)
+constexpr int MOP = 36;                         // floats per result row (144 B: the float4 writes of 16 rows hit 64 banks)
+constexpr int MPB_OUT = 2336 / 4;               // floats per result plane (>= 16 * 36)
+static_assert(MPB_IN >= MIY * MIP && MPB_OUT >= MTY * MOP, "plane sizes");
+
+template <typename T> struct DwVec;
+template <> struct DwVec<bf16_t> { typedef bf16x8 v8; };
+template <> struct DwVec<f16_t> { typedef f16x8 v8; };
+__device__ __forceinline__ f32x4 dw_mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 dw_mfma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+template <typename T>
+__global__ __launch_bounds__(512, 4) void dwconv7x7_mfma_kernel(const T* __restrict__ x, long ldx,
+                                                                 const float* __restrict__ w,
+                                                                 const float* __restrict__ bias,
+                                                                 const T* __restrict__ addend, long ldadd,
+                                                                 T* __restrict__ y, long ldy, int B, int H, int W, int Cp,
+                                                                 int cslices, int tiles_x, int tiles_y, int wg_per_slice) {
+  typedef typename DwVec<T>::v8 v8;
+  __shared__ __attribute__((aligned(16))) T in_planes[16 * MPB_IN];
+  __shared__ __attribute__((aligned(16))) float out_planes[16 * MPB_OUT];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  // workgroup -> (channel slice, spatial walker).  The slices of one walker index sit on one XCD (blockIdx % 8 equal) and
+  // walk the same tiles at the same time, so the 16-channel pieces of a pixel's row are assembled in that XCD's L2.
+  const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+  const int slice = rest % cslices;
+  const int walker = (rest / cslices) * 8 + xcd;
+  const int c0 = slice * 16;
+  const int nsp = tiles_x * tiles_y * B;  // spatial tiles
+  if (walker >= wg_per_slice) return;
+  constexpr int NTHR = 512;
+  constexpr int NITEM = MIY * MIX * 2, NSTG = (NITEM + NTHR - 1) / NTHR;
+  for (int i = tid; i < 16 * MPB_IN / 2; i += NTHR) reinterpret_cast<unsigned*>(in_planes)[i] = 0u;  // margins stay zero
+
+  // band matrices of this wave's 4 channels: A_ky[i][k], lane = (i, k = 8g .. 8g+7).  The slice's 49 x 16 weights go
+  // through LDS (the result planes are idle): per-lane gathers straight from global memory would keep 224 loads in flight
+  for (int i = tid; i < 49 * 16; i += NTHR) {
+    const int tap = i >> 4, cl = i & 15;
+    out_planes[i] = (c0 + cl < Cp) ? w[(long)tap * Cp + c0 + cl] : 0.f;
+  }
+  __syncthreads();
+  v8 af[2][7];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    const int cl = wave * 2 + cc;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+      v8 a;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int tap = 8 * g + e - li - 5;
+        const bool ok = tap >= 0 && tap < 7;
+        const float v = out_planes[((ky * 7 + (ok ? tap : 0)) << 4) + cl];
+        a[e] = (T)(ok ? v : 0.f);
+      }
+      af[cc][ky] = a;
+    }
+    asm volatile("" ::: "memory");  // one channel's 56 reads at a time
+  }
+  float bv[2];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) bv[cc] = (bias && c0 + wave * 2 + cc < Cp) ? bias[c0 + wave * 2 + cc] : 0.f;
+
+  auto decode = [&](int t, int& b, int& y0, int& x0) {
+    const int tx = t % tiles_x;
+    const int q = t / tiles_x;
+    const int ty = q % tiles_y;
+    b = q / tiles_y;
+    y0 = ty * MTY;
+    x0 = tx * MTX;
+  };
+  // halo tile: item = (pixel, 8-channel chunk of the slice); loads of a thread are issued together
+  uint4 sv[NSTG];
+  auto fetch = [&](int t) {
+    int b, y0, x0;
+    decode(t, b, y0, x0);
+#pragma unroll
+    for (int k = 0; k < NSTG; ++k) {
+      const int it = tid + k * NTHR;
+      const int chunk = it & 1, q = it >> 1;
+      const int iy = q / MIX, ix = q - iy * MIX;
+      const int gy = y0 + iy - 3, gx = x0 + ix - 3;
+      const int c = c0 + chunk * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (it < NITEM && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cp && !(DW_ABL & 8))
+        v = *reinterpret_cast<const uint4*>(x + (((long)b * H + gy) * W + gx) * ldx + c);
+      sv[k] = v;
+    }
+  };
+  // channel 8*chunk + k of the slice -> plane 2k + chunk (the two chunk lanes of a pixel land 24 banks apart)
+  auto stage = [&]() {
+#pragma unroll
+    for (int k = 0; k < NSTG; ++k) {
+      const int it = tid + k * NTHR;
+      if (it < NITEM && !(DW_ABL & 2)) {
+        const int chunk = it & 1, q = it >> 1;
+        const int iy = q / MIX, ix = q - iy * MIX;
+        unsigned short* dst = reinterpret_cast<unsigned short*>(in_planes) + chunk * MPB_IN + iy * MIP + ix + 5;
+        const unsigned wd[4] = {sv[k].x, sv[k].y, sv[k].z, sv[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dst[(2 * e) * 2 * MPB_IN] = (unsigned short)(wd[e] & 0xffffu);
+          dst[(2 * e + 1) * 2 * MPB_IN] = (unsigned short)(wd[e] >> 16);
+        }
+      }
+    }
+  };
+
+  int t = walker;
+  if (t >= nsp) return;
+  fetch(t);
+  __syncthreads();  // zero fill done, the weight table in the result planes has been read
+  stage();
+  __syncthreads();
+  for (; t < nsp; t += wg_per_slice) {
+    int b, y0, x0;
+    decode(t, b, y0, x0);
+    const bool more = t + wg_per_slice < nsp;
+    if (more) fetch(t + wg_per_slice);  // in flight behind this tile's matrix products
+
+    // ---- compute: 7 MFMAs per (channel, 16-column group); D[i][j]: lane holds out x = 4g .. 4g+3 of row j = li
+#pragma unroll
+    for (int cc = 0; cc < ((DW_ABL & 1) ? 0 : 2); ++cc) {
+      const int cl = wave * 2 + cc;
+      const int P = (cl & 7) * 2 + (cl >> 3);
+      const T* pl = in_planes + P * MPB_IN + li * MIP + 8 * g;
+#pragma unroll
+      for (int xg = 0; xg < 2; ++xg) {
+        f32x4 acc = {bv[cc], bv[cc], bv[cc], bv[cc]};
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+          const v8 bf = *reinterpret_cast<const v8*>(pl + ky * MIP + xg * 16);
+          acc = dw_mfma(af[cc][ky], bf, acc);
+        }
+        *reinterpret_cast<f32x4*>(out_planes + P * MPB_OUT + li * MOP + xg * 16 + 4 * g) = acc;
+        asm volatile("" ::: "memory");  // keep the 7 fragment reads of the next group here (hoisting all 56 spills)
+      }
+    }
+    // LDS-only barrier: __syncthreads() would also drain the vector-memory queue, i.e. wait for the prefetch just issued
+    // and for the previous tile's stores at every tile (6 us per tile instead of ~2)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // results complete; the input planes are free
+    asm volatile("" ::: "memory");
+
+    // ---- fp32 result planes -> 16-byte channel chunks of y (+ the residual): item = (pixel, chunk)
+    constexpr int NOUT = (DW_ABL & 4) ? 0 : MTY * MTX * 2 / NTHR;
+#pragma unroll 1
+    for (int k = 0; k < NOUT; ++k) {
+      const int it = tid + k * NTHR;
+      const int chunk = it & 1, q = it >> 1;
+      const int oy = q / MTX, ox = q - oy * MTX;
+      const int gy = y0 + oy, gx = x0 + ox;
+      const int c = c0 + chunk * 8;
+      if (gy < H && gx < W && c < Cp) {
+        const long pix = ((long)b * H + gy) * W + gx;
+        float o[8];
+        if (addend) load8(addend + pix * ldadd + c, o);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = 0.f;
+        }
+        const float* src = out_planes + chunk * MPB_OUT + oy * MOP + ox;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += src[e * 2 * MPB_OUT];
+        store8(y + pix * ldy + c, o);
+      }
+    }
+    if (!more) break;
+    stage();          // next halo tile (registers) -> input planes
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // ... visible, and the result planes have been read
+    asm volatile("" ::: "memory");
+  }
+}
+
 // partial[p][tap][c] = sum over the workgroup's pixels of dy[pix][c] * x[pix + tap][c]; row 49 = sum dy
 template <typename T>
 __global__ __launch_bounds__(256, 2) void dwconv7x7_wgrad_kernel(const T* __restrict__ x, long ldx,
@@ -479,6 +671,27 @@ extern "C" int vkas_dwconv7x7_fwd(const void* x, long ldx, const float* w, const
   // staging all on the same two waves per SIMD it measures 300 us at stage 0 against 252 us of the kernel above
   // (profiles/bench_dw.py; ablations in DESIGN.md): both sit on the fp32 VALU roof, not on HBM.
   static const bool planar = getenv("VKAS_DW_PLANAR") != nullptr;
+  static const bool valu = getenv("VKAS_DW_VALU") != nullptr;  // A/B switch: the round-1 vector-ALU kernel for 16-bit types too
+  if ((dtype == VKAS_BF16 || dtype == VKAS_F16) && !valu && !planar) {
+    const int cslices = (Cp + 15) / 16;
+    const int tiles_x = (W + MTX - 1) / MTX, tiles_y = (H + MTY - 1) / MTY;
+    const long nsp = (long)tiles_x * tiles_y * B;
+    VKAS_CHECK(nsp < (1L << 30), "vkas_dwconv7x7_fwd: too many tiles");
+    // two persistent workgroups per CU: 512 / cslices walkers per slice (a multiple of 8: whole walker groups per XCD)
+    long wps = 512 / cslices;
+    wps = wps / 8 * 8;
+    if (wps < 8) wps = 8;
+    if (wps > nsp) wps = (nsp + 7) / 8 * 8;
+    const unsigned grid = (unsigned)(wps * cslices);
+#define VKAS_DWM(TT)                                                                                                      \
+  dwconv7x7_mfma_kernel<TT><<<grid, 512, 0, vkas_stream(stream)>>>((const TT*)x, ldx, w, bias, (const TT*)addend, ldadd, (TT*)y, \
+                                                                  ldy, B, H, W, Cp, cslices, tiles_x, tiles_y, (int)wps)
+    if (dtype == VKAS_BF16) VKAS_DWM(bf16_t);
+    else VKAS_DWM(f16_t);
+#undef VKAS_DWM
+    VKAS_LAUNCH_CHECK("dwconv7x7_mfma");
+    return VKAS_OK;
+  }
   if (dtype == VKAS_BF16 && planar) {
     const int cslices = (Cp + 31) / 32;
     const int tiles_x = (W + PTX - 1) / PTX, tiles_y = (H + PTY - 1) / PTY;

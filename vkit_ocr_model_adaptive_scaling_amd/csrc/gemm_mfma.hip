@@ -983,14 +983,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const elem_t* _
   const unsigned q8 = total >> 3, r8 = total & 7u;
   const unsigned work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
   const unsigned tile = work % tiles;
-  // within a split: n tile slowest.  An XCD runs 32 workgroups at a time, i.e. about half the 27 - 63 tiles of a split:
-  // with the 9 (ky, channel block) tiles of an n tile adjacent, the co-resident set shares each dy slice 9 ways and each x
-  // slab 3 - 4 ways through L2; with the n tiles fastest (round 1) every slice and slab was fetched by both halves
-  // (rocprofv3: 14.2 GB per launch against 4.1 GB of operands).
-  const unsigned per_n = 3u * ncb;
-  const int n0 = (int)(tile / per_n) * BNn;
-  const int ky = (int)((tile % per_n) % 3u);
-  const int cb = (int)((tile % per_n) / 3u);
+  // (n tiles fastest within a split; the 9 (ky, channel block) tiles of an n tile adjacent instead - "n tile slowest" -
+  // was measured in round 2 and is 2-3 % slower although it halves the dy re-reads: the kernel is not HBM bound)
+  const int n0 = (int)(tile % ntn) * BNn;
+  const int ky = (int)((tile / ntn) % 3u);
+  const int cb = (int)(tile / (ntn * 3u));
   const long total_chunks = M / WG_ROWS;
   const long c_beg = (long)(work / tiles) * chunks_per_split;
   const int nchunks = (int)((c_beg + chunks_per_split <= total_chunks ? chunks_per_split : total_chunks - c_beg));

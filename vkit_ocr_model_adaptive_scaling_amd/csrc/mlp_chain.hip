@@ -1,5 +1,5 @@
 // ConvNeXt MLP as ONE kernel per direction (model/convnext.py:33-35,54-58: Linear(C,4C) -> GELU -> Linear(4C,C) ->
-// layer scale -> stochastic depth -> residual), for C <= 256: the (pixels x 4C) intermediate never round-trips HBM
+// layer scale -> stochastic depth -> residual), for C <= 512: the (pixels x 4C) intermediate never round-trips HBM
 // between the two GEMMs.
 //
 //   forward : h = yn W1^T + b1 (stored once, bf16, for backward); g = gelu(h) stays in registers;
@@ -408,9 +408,9 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
 
 // KS (32-wide K steps covering C) and rows per wave for a channel count, 0 when the chain kernels do not cover it
 static int chain_ks(int C) {
-  if (C <= 0 || C % 8 != 0 || C > 256) return 0;
+  if (C <= 0 || C % 8 != 0 || C > 512) return 0;
   const int ks = (C + 31) / 32;
-  return ks <= 4 ? ks : (ks <= 6 ? 6 : 8);
+  return ks <= 4 ? ks : (ks <= 6 ? 6 : (ks <= 8 ? 8 : (ks <= 12 ? 12 : 16)));
 }
 
 template <typename T, int MODE>
@@ -429,8 +429,12 @@ static int launch_chain(const ChainArgs& a, hipStream_t st) {
     case 4: VKAS_CHAIN(4, 2, 2) break;
     case 6: VKAS_CHAIN(6, 2, 2) break;
     case 8: VKAS_CHAIN(8, 2, 1) break;
+    // 384 / 512 channels (stage 2 of Tiny / Base): one workgroup of four 512-register waves per CU; the weight images
+    // (49 / 65 KB per chunk) stream from L2, 128 rows per workgroup keep that stream under the L2 -> LDS rate
+    case 12: VKAS_CHAIN(12, 2, 1) break;
+    case 16: VKAS_CHAIN(16, 2, 1) break;
     default:
-      vkas_set_error("vkas_mlp_chain: C=%d is not covered (multiple of 8, <= 256)", a.C);
+      vkas_set_error("vkas_mlp_chain: C=%d is not covered (multiple of 8, <= 512)", a.C);
       return VKAS_E_ARG;
   }
 #undef VKAS_CHAIN
@@ -449,7 +453,7 @@ extern "C" int vkas_mlp_chain_pack(const float* w1, const float* w2, const float
   VKAS_CHECK(w1 && w2 && img && vkas_aligned16(img) && (mode != 0 || (b1 && vkas_aligned16(b1))),
              "vkas_mlp_chain_pack: null / misaligned pointer");
   const int ks = chain_ks(C);
-  VKAS_CHECK(ks > 0, "vkas_mlp_chain_pack: C=%d is not covered (multiple of 8, <= 256)", C);
+  VKAS_CHECK(ks > 0, "vkas_mlp_chain_pack: C=%d is not covered (multiple of 8, <= 512)", C);
   VKAS_CHECK(mode == 0 || mode == 1, "vkas_mlp_chain_pack: mode must be 0 (forward) or 1 (backward)");
   VKAS_CHECK(dtype == VKAS_BF16 || dtype == VKAS_F16, "vkas_mlp_chain_pack: 16-bit storage types only");
   const long pieces = (long)(4 * C / 32) * (chain_img_elems(ks) / 8);
@@ -472,7 +476,7 @@ extern "C" int vkas_mlp_chain_fwd(const void* yn, long ldyn, const void* img, co
                                   void* z, long ldz, void* out, long ldo, long M, int C, int dtype, void* stream) {
   const char* who = "vkas_mlp_chain_fwd";
   VKAS_CHECK(dtype == VKAS_BF16 || dtype == VKAS_F16, "%s: 16-bit storage types only", who);
-  VKAS_CHECK(chain_ks(C) > 0, "%s: C=%d is not covered (multiple of 8, <= 256)", who, C);
+  VKAS_CHECK(chain_ks(C) > 0, "%s: C=%d is not covered (multiple of 8, <= 512)", who, C);
   VKAS_CHECK(img && b2 && colscale && vkas_aligned16(img) && vkas_aligned16(b2) && vkas_aligned16(colscale),
              "%s: null / misaligned parameter", who);
   VKAS_CHECK(M >= 0 && rows_per_image > 0, "%s: bad sizes", who);
@@ -498,7 +502,7 @@ extern "C" int vkas_mlp_chain_bwd(const void* dz, long lddz, const void* img_t, 
                                   void* dyn, long lddyn, long M, int C, int dtype, void* stream) {
   const char* who = "vkas_mlp_chain_bwd";
   VKAS_CHECK(dtype == VKAS_BF16 || dtype == VKAS_F16, "%s: 16-bit storage types only", who);
-  VKAS_CHECK(chain_ks(C) > 0, "%s: C=%d is not covered (multiple of 8, <= 256)", who, C);
+  VKAS_CHECK(chain_ks(C) > 0, "%s: C=%d is not covered (multiple of 8, <= 512)", who, C);
   VKAS_CHECK(img_t && vkas_aligned16(img_t) && M >= 0, "%s: bad arguments", who);
   int rc;
   if ((rc = chain_check_act(who, dz, lddz, C)) || (rc = chain_check_act(who, h, ldh, 4 * C)) || (rc = chain_check_act(who, dh, lddh, 4 * C)) ||

@@ -154,7 +154,7 @@ _NO_CHAIN = os.environ.get('VKAS_NO_MLP_CHAIN') is not None  # A/B switch: force
 
 
 def mlp_chain_eligible(x: torch.Tensor, C: int) -> bool:
-    """The fused ConvNeXt MLP kernels (csrc/mlp_chain.hip) cover bf16 activations with C % 8 == 0, C <= 256."""
+    """The fused ConvNeXt MLP kernels (csrc/mlp_chain.hip) cover 16-bit activations with C % 8 == 0, C <= 512."""
     return (not _NO_CHAIN and x.dtype in _MFMA_DTYPES and x.shape[3] == C
             and lib.vkas_mlp_chain_image_elems(C) > 0)
 
@@ -784,7 +784,7 @@ class HeadsFused(Function):
 
 class ConvNextLayer(Function):
     """ConvNextBlockLayer.forward (model/convnext.py:29-59): dw7x7 -> LN -> MLP with the layer-scale / stochastic-depth /
-    residual epilogue.  bf16, C % 8 == 0, C <= 256: the MLP is ONE kernel per direction (csrc/mlp_chain.hip; the 4C-wide
+    residual epilogue.  bf16 / fp16, C % 8 == 0, C <= 512: the MLP is ONE kernel per direction (csrc/mlp_chain.hip; the 4C-wide
     activation is written once for backward and never read back between the two matrix products); otherwise
     GEMM(C,4C)+GELU -> GEMM(4C,C)+epilogue.  ``rowscale`` is the per-sample keep mask already divided by the keep
     probability (:41-53) or None."""
