@@ -216,7 +216,7 @@ def test_convnext_layer(shape, dtype):
     assert r < gtol, ('dx', r)
 
 
-@pytest.mark.parametrize('C', [16, 96, 192, 384])
+@pytest.mark.parametrize('C', [16, 96, 192, 384, 512])
 def test_mlp_chain_matches_two_gemm_path(C):
     """The fused MLP kernels against the two-GEMM layer path they replace (same bf16 inputs; the two differ only in
     where fp32 values are rounded to bf16): outputs and every gradient, ragged M (not a multiple of the 256/128-row tile),
@@ -233,8 +233,10 @@ def test_mlp_chain_matches_two_gemm_path(C):
     mask = torch.tensor([1.25, 0.0, 1.0], device='cuda')
     cot = torch.randn(B, H, W, C, device='cuda').to(torch.bfloat16)
     res = {}
+    max_c = ops._CHAIN_MAX_C
     for chain in (True, False):
         ops._NO_CHAIN = not chain
+        ops._CHAIN_MAX_C = 512  # the wide instantiations are not the default path (no faster than two GEMMs)
         try:
             ps = [t.clone().cuda().requires_grad_(True) for t in base]
             xa = x.clone().requires_grad_(True)
@@ -244,6 +246,7 @@ def test_mlp_chain_matches_two_gemm_path(C):
             res[chain] = [y.detach()] + [xa.grad] + [p.grad for p in ps]
         finally:
             ops._NO_CHAIN = False
+            ops._CHAIN_MAX_C = max_c
     for name, a, b in zip(['out', 'dx'] + names, res[True], res[False]):
         assert rel_err(a, b) < 1.5e-2, (name, rel_err(a, b))
     assert float(res[True][0][1].float().sub(x[1].float()).abs().max()) == 0.0, 'dropped sample must pass through'

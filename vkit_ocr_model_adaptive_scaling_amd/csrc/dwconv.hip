@@ -543,6 +543,178 @@ __global__ __launch_bounds__(512, 4) void dwconv7x7_mfma_kernel(const T* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 16-bit weight gradient on the matrix cores: gw[c][ky][kx] = sum_{y,x} dy[y][x][c] * x[y+ky-3][x+kx-3][c].
+// For one channel, one input row r and the 32 columns of a tile,
+//      D[i][j] += A[i][k] * B[k][j],   A[i][k] = dy[r - 3 + i][x0 + k]        (i < 7: the 7 output rows that see row r),
+//                                      B[k][j] = x[r][x0 + k + j - 3]         (j < 7: the 7 lags; a Toeplitz matrix),
+// accumulates all 49 taps at once: D[i][j] -> gw[ky = 6 - i][kx = j].  Column j = 7 of B is all ones, so D[3][7] collects
+// sum dy (the bias gradient, counted once: i = 3 is the row r itself).  22 MFMAs per channel and tile instead of
+// 16 * 32 * 49 FMAs.  A is a 16-byte aligned row read; B needs 8 consecutive elements at an element offset 8g + j that
+// is odd for odd j: every lane reads 5 dwords and funnels them by 0 or 16 bits (v_alignbit).  Same persistent
+// 16-channel-slice workgroups as the forward kernel; the 4-register accumulator of a channel lives across all tiles of the
+// walker and leaves as one partial row per walker (summed by the finalize kernel).
+constexpr int WXP = 40;                          // elements per staged x row (38 halo columns + 2)
+constexpr int WDP = 48;                          // elements per staged dy row (32 + 16: 96-byte pitch)
+constexpr int WPB_X = MIY * WXP;                 // elements per x plane
+constexpr int WPB_D = MTY * WDP;                 // elements per dy plane
+
+template <typename T>
+__global__ __launch_bounds__(512, 4) void dwconv7x7_wgrad_mfma_kernel(const T* __restrict__ x, long ldx,
+                                                                       const T* __restrict__ dy, long lddy,
+                                                                       float* __restrict__ partial, int B, int H, int W,
+                                                                       int Cp, int cslices, int tiles_x, int tiles_y,
+                                                                       int wg_per_slice) {
+  typedef typename DwVec<T>::v8 v8;
+  constexpr int NTHR = 512;
+  __shared__ __attribute__((aligned(16))) T xp[16 * WPB_X];
+  __shared__ __attribute__((aligned(16))) T dp[16 * WPB_D + 64];  // + a zero row for the A lanes outside the tile
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+  const int slice = rest % cslices;
+  const int walker = (rest / cslices) * 8 + xcd;
+  const int c0 = slice * 16;
+  const int nsp = tiles_x * tiles_y * B;
+  if (walker >= wg_per_slice) return;
+  constexpr int NXI = MIY * MIX * 2, NXS = (NXI + NTHR - 1) / NTHR;   // x halo items (pixel, chunk)
+  constexpr int NDI = MTY * MTX * 2, NDS = NDI / NTHR;                 // dy items
+  for (int i = tid; i < 32; i += NTHR) reinterpret_cast<unsigned*>(dp + 16 * WPB_D)[i] = 0u;
+  for (int i = tid; i < 16 * WPB_X / 2; i += NTHR) reinterpret_cast<unsigned*>(xp)[i] = 0u;  // columns 38, 39 stay zero
+
+  auto decode = [&](int t, int& b, int& y0, int& x0) {
+    const int tx = t % tiles_x;
+    const int q = t / tiles_x;
+    const int ty = q % tiles_y;
+    b = q / tiles_y;
+    y0 = ty * MTY;
+    x0 = tx * MTX;
+  };
+  uint4 sx[NXS], sd[NDS];
+  auto fetch = [&](int t) {
+    int b, y0, x0;
+    decode(t, b, y0, x0);
+#pragma unroll
+    for (int k = 0; k < NXS; ++k) {
+      const int it = tid + k * NTHR;
+      const int chunk = it & 1, q = it >> 1;
+      const int iy = q / MIX, ix = q - iy * MIX;
+      const int gy = y0 + iy - 3, gx = x0 + ix - 3;
+      const int c = c0 + chunk * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (it < NXI && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cp)
+        v = *reinterpret_cast<const uint4*>(x + (((long)b * H + gy) * W + gx) * ldx + c);
+      sx[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NDS; ++k) {
+      const int it = tid + k * NTHR;
+      const int chunk = it & 1, q = it >> 1;
+      const int oy = q / MTX, ox = q - oy * MTX;
+      const int gy = y0 + oy, gx = x0 + ox;
+      const int c = c0 + chunk * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (gy < H && gx < W && c < Cp) v = *reinterpret_cast<const uint4*>(dy + (((long)b * H + gy) * W + gx) * lddy + c);
+      sd[k] = v;
+    }
+  };
+  // channel 8*chunk + k of the slice -> plane 2k + chunk
+  auto scatter8 = [&](unsigned short* dst, int plane_elems, const uint4& v) {
+    const unsigned wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dst[(2 * e) * 2 * plane_elems] = (unsigned short)(wd[e] & 0xffffu);
+      dst[(2 * e + 1) * 2 * plane_elems] = (unsigned short)(wd[e] >> 16);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int k = 0; k < NXS; ++k) {
+      const int it = tid + k * NTHR;
+      if (it < NXI) {
+        const int chunk = it & 1, q = it >> 1;
+        const int iy = q / MIX, ix = q - iy * MIX;
+        scatter8(reinterpret_cast<unsigned short*>(xp) + chunk * WPB_X + iy * WXP + ix, WPB_X, sx[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NDS; ++k) {
+      const int it = tid + k * NTHR;
+      const int chunk = it & 1, q = it >> 1;
+      const int oy = q / MTX, ox = q - oy * MTX;
+      scatter8(reinterpret_cast<unsigned short*>(dp) + chunk * WPB_D + oy * WDP + ox, WPB_D, sd[k]);
+    }
+  };
+
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  // per-lane constants of the B gather: element offset 8g + j inside an x row (j clamped to a valid lag), funnel shift
+  const int jl = li < 7 ? li : 6;
+  const int eo = 8 * g + jl;
+  const unsigned sh = (eo & 1) ? 16u : 0u;
+  v8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
+
+  int t = walker;
+  if (t < nsp) {
+    fetch(t);
+    __syncthreads();  // zero fills done
+    stage();
+    __syncthreads();
+    for (; t < nsp; t += wg_per_slice) {
+      const bool more = t + wg_per_slice < nsp;
+      if (more) fetch(t + wg_per_slice);
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int cl = wave * 2 + cc;
+        const int P = (cl & 7) * 2 + (cl >> 3);
+        const unsigned* xrow = reinterpret_cast<const unsigned*>(xp + P * WPB_X) + (eo >> 1);
+        const T* dpl = dp + P * WPB_D + 8 * g;
+        const T* zrow = dp + 16 * WPB_D + 8 * g;
+#pragma unroll 2
+        for (int rr = 0; rr < MIY; ++rr) {  // input row r = y0 - 3 + rr
+          // A: dy row (rr - 6 + i) of the tile for i < 7, zeros elsewhere
+          const int p = rr - 6 + li;
+          const T* ap = (li < 7 && (unsigned)p < (unsigned)MTY) ? dpl + p * WDP : zrow;
+          const v8 af = *reinterpret_cast<const v8*>(ap);
+          // B: 8 elements of x row rr starting at element eo
+          const unsigned* bp = xrow + rr * (WXP / 2);
+          const unsigned d0 = bp[0], d1 = bp[1], d2 = bp[2], d3 = bp[3], d4 = bp[4];
+          union { unsigned u[4]; v8 v; } bf;
+          bf.u[0] = __builtin_amdgcn_alignbit(d1, d0, sh);
+          bf.u[1] = __builtin_amdgcn_alignbit(d2, d1, sh);
+          bf.u[2] = __builtin_amdgcn_alignbit(d3, d2, sh);
+          bf.u[3] = __builtin_amdgcn_alignbit(d4, d3, sh);
+          acc[cc] = dw_mfma(af, li == 7 ? ones : bf.v, acc[cc]);
+        }
+      }
+      if (!more) break;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave is done with the planes (LDS-only barrier: the prefetch stays in flight)
+      asm volatile("" ::: "memory");
+      stage();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  }
+  // partial row of this walker: [tap = ky*7 + kx][Cp] + row 49 = bias; D[i][j]: lane holds i = 4g + r, j = li
+  float* prow = partial + (long)walker * 50 * Cp;
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    const int ch = c0 + wave * 2 + cc;
+    if (ch >= Cp) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * g + r;
+      if (i < 7 && li < 7) prow[(long)((6 - i) * 7 + li) * Cp + ch] = acc[cc][r];
+      if (i == 3 && li == 7) prow[49L * Cp + ch] = acc[cc][r];
+    }
+  }
+}
+
 // partial[p][tap][c] = sum over the workgroup's pixels of dy[pix][c] * x[pix + tap][c]; row 49 = sum dy
 template <typename T>
 __global__ __launch_bounds__(256, 2) void dwconv7x7_wgrad_kernel(const T* __restrict__ x, long ldx,
@@ -647,6 +819,18 @@ __global__ __launch_bounds__(256, 2) void dwconv7x7_wgrad_kernel(const T* __rest
 
 }  // namespace
 
+// persistent walkers per 16-channel slice of the matrix-core kernels: two workgroups per CU in all, whole groups of 8
+// (one per XCD), never more than there are spatial tiles (rounded up to 8)
+static long dw_mfma_walkers(int B, int H, int W, int Cp) {
+  const int cslices = (Cp + 15) / 16;
+  const long nsp = (long)vkas_cdiv(W, MTX) * vkas_cdiv(H, MTY) * B;
+  long wps = 512 / cslices;
+  wps = wps / 8 * 8;
+  if (wps < 8) wps = 8;
+  if (wps > nsp) wps = (nsp + 7) / 8 * 8;
+  return wps;
+}
+
 static int dw_check(const char* who, const void* x, long ldx, int B, int H, int W, int Cp) {
   VKAS_CHECK(x && vkas_aligned16(x), "%s: null/misaligned tensor", who);
   VKAS_CHECK(B >= 0 && H > 0 && W > 0 && Cp > 0 && Cp % 8 == 0, "%s: bad dims B=%d H=%d W=%d Cp=%d", who, B, H, W, Cp);
@@ -677,11 +861,7 @@ extern "C" int vkas_dwconv7x7_fwd(const void* x, long ldx, const float* w, const
     const int tiles_x = (W + MTX - 1) / MTX, tiles_y = (H + MTY - 1) / MTY;
     const long nsp = (long)tiles_x * tiles_y * B;
     VKAS_CHECK(nsp < (1L << 30), "vkas_dwconv7x7_fwd: too many tiles");
-    // two persistent workgroups per CU: 512 / cslices walkers per slice (a multiple of 8: whole walker groups per XCD)
-    long wps = 512 / cslices;
-    wps = wps / 8 * 8;
-    if (wps < 8) wps = 8;
-    if (wps > nsp) wps = (nsp + 7) / 8 * 8;
+    const long wps = dw_mfma_walkers(B, H, W, Cp);
     const unsigned grid = (unsigned)(wps * cslices);
 #define VKAS_DWM(TT)                                                                                                      \
   dwconv7x7_mfma_kernel<TT><<<grid, 512, 0, vkas_stream(stream)>>>((const TT*)x, ldx, w, bias, (const TT*)addend, ldadd, (TT*)y, \
@@ -720,7 +900,10 @@ static long dw_wgrad_parts(int B, int H, int W) {
 }
 
 extern "C" size_t vkas_dwconv7x7_wgrad_ws_bytes(int B, int H, int W, int Cp) {
-  return (size_t)dw_wgrad_parts(B, H, W) * 50 * (size_t)Cp * sizeof(float);
+  long parts = dw_wgrad_parts(B, H, W);
+  const long walkers = dw_mfma_walkers(B, H, W, Cp);
+  if (walkers > parts) parts = walkers;
+  return (size_t)parts * 50 * (size_t)Cp * sizeof(float);
 }
 
 extern "C" int vkas_dwconv7x7_wgrad(const void* x, long ldx, const void* dy, long lddy, float* gw, float* gb,
@@ -737,6 +920,25 @@ extern "C" int vkas_dwconv7x7_wgrad(const void* x, long ldx, const void* dy, lon
     (void)hipMemsetAsync(gw, 0, 49L * Cp * sizeof(float), st);
     (void)hipMemsetAsync(gb, 0, (long)Cp * sizeof(float), st);
     return VKAS_OK;
+  }
+  static const bool valu = getenv("VKAS_DW_VALU") != nullptr;  // A/B switch: the round-1 vector-ALU kernel
+  if ((dtype == VKAS_BF16 || dtype == VKAS_F16) && !valu) {
+    const int cslices = (Cp + 15) / 16;
+    const int tiles_x = (W + MTX - 1) / MTX, tiles_y = (H + MTY - 1) / MTY;
+    VKAS_CHECK((long)tiles_x * tiles_y * B < (1L << 30), "vkas_dwconv7x7_wgrad: too many tiles");
+    const long wps = dw_mfma_walkers(B, H, W, Cp);
+    const unsigned grid = (unsigned)(wps * cslices);
+    if (dtype == VKAS_BF16)
+      dwconv7x7_wgrad_mfma_kernel<bf16_t><<<grid, 512, 0, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, ws, B, H, W, Cp,
+                                                               cslices, tiles_x, tiles_y, (int)wps);
+    else
+      dwconv7x7_wgrad_mfma_kernel<f16_t><<<grid, 512, 0, st>>>((const f16_t*)x, ldx, (const f16_t*)dy, lddy, ws, B, H, W, Cp,
+                                                              cslices, tiles_x, tiles_y, (int)wps);
+    VKAS_LAUNCH_CHECK("dwconv7x7_wgrad_mfma");
+    if (gb == gw + 49L * Cp) return vkas_colreduce_finalize(ws, wps, 50 * Cp, 50 * Cp, gw, 0, st);
+    rc = vkas_colreduce_finalize(ws, wps, 49 * Cp, 50 * Cp, gw, 0, st);
+    if (rc) return rc;
+    return vkas_colreduce_finalize(ws + 49L * Cp, wps, Cp, 50 * Cp, gb, 0, st);
   }
   const long P = dw_wgrad_parts(B, H, W);
   VKAS_DISPATCH_DTYPE(dtype, "vkas_dwconv7x7_wgrad", {

@@ -88,8 +88,7 @@ __device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head,
 #pragma unroll
     for (int c = 0; c < 8; ++c) s += (c0 + c < C) ? v[i][c] : 0.f;
   }
-#pragma unroll
-  for (int o = LPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  s = group_sum<LPR>(s);
   const float mean = s / (float)C;
   float q = 0.f;
 #pragma unroll
@@ -101,8 +100,7 @@ __device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head,
       q += (c0 + c < C) ? d * d : 0.f;
     }
   }
-#pragma unroll
-  for (int o = LPR >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  q = group_sum<LPR>(q);
   const float rstd = rsqrtf(q / (float)C + 1e-6f);
   float pr[4] = {0.f, 0.f, 0.f, 0.f};
   elem_t* zout = reinterpret_cast<elem_t*>(e.out);
@@ -126,8 +124,7 @@ __device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head,
   }
 #pragma unroll
   for (int qq = 0; qq < 4; ++qq)
-#pragma unroll
-    for (int o = LPR >> 1; o > 0; o >>= 1) pr[qq] += __shfl_xor(pr[qq], o, 64);
+    pr[qq] = group_sum<LPR>(pr[qq]);
   if (j == 0 && m < M) {
     const float4 bp = *reinterpret_cast<const float4*>(hp + 6 * pw);
     float* po = e.head.proj + ((long)head * M + m) * 8;

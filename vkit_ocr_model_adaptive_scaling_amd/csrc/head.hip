@@ -181,11 +181,8 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-#pragma unroll
-      for (int o = G >> 1; o > 0; o >>= 1) {
-        s1[r] += __shfl_xor(s1[r], o, 64);
-        s2[r] += __shfl_xor(s2[r], o, 64);
-      }
+      s1[r] = group_sum<G>(s1[r]);
+      s2[r] = group_sum<G>(s2[r]);
       s1[r] *= invC;
       s2[r] *= invC;
     }

@@ -15,8 +15,14 @@ namespace {
 
 constexpr int MAXV_LIMIT = 4;  // vectors per lane: Cp <= 8 * 64 * 4 = 2048
 
+// runtime group width (wave-uniform): the same DPP / swizzle steps as group_sum<W> in vkas_common.h
 __device__ __forceinline__ float group_sum(float v, int G) {
-  for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if (G >= 2) v += dpp_f<0xB1>(v);
+  if (G >= 4) v += dpp_f<0x4E>(v);
+  if (G >= 8) v += dpp_f<0x141>(v);
+  if (G >= 16) v += dpp_f<0x140>(v);
+  if (G >= 32) v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+  if (G >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
 

@@ -185,11 +185,25 @@ template <> __device__ __forceinline__ float dgelu_t<bf16_t>(float x) {
   return fmaf(xc, p, 0.5f);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Sum over aligned groups of W consecutive lanes (W = 2 .. 64), result in every lane of the group.  Up to 16 lanes the
+// exchange is a DPP operand of the add (quad permutes, half-row / row mirror: plain VALU speed); 32 adds one ds_swizzle
+// (lane ^ 16) and 64 one ds_bpermute.  __shfl_xor lowers EVERY step to ds_bpermute_b32 (an LDS-crossbar round trip of ~60
+// cycles): the per-row LayerNorm / head reductions were chains of 3-5 of them.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int W> __device__ __forceinline__ float group_sum(float v) {
+  static_assert(W == 1 || W == 2 || W == 4 || W == 8 || W == 16 || W == 32 || W == 64, "group width");
+  if constexpr (W >= 2) v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  if constexpr (W >= 4) v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  if constexpr (W >= 8) v += dpp_f<0x141>(v);   // row_half_mirror
+  if constexpr (W >= 16) v += dpp_f<0x140>(v);  // row_mirror
+  if constexpr (W >= 32) v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // lane ^ 16
+  if constexpr (W >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
+
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

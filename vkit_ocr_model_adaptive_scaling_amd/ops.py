@@ -153,9 +153,15 @@ def _cached_pack_pair(a: torch.Tensor, b: torch.Tensor, key, build):
 _NO_CHAIN = os.environ.get('VKAS_NO_MLP_CHAIN') is not None  # A/B switch: force the two-GEMM layer path
 
 
+# The kernels exist up to 512 channels, but beyond 256 a workgroup streams 49 - 65 KB of weights per 32 hidden units
+# through LDS with one wave per SIMD and measured no faster than the two-GEMM path (stage 2 of ConvNeXt-T: 0.31 ms per
+# layer and direction either way), so the layer op uses them up to 256 channels; tests raise the limit to cover the rest.
+_CHAIN_MAX_C = int(os.environ.get('VKAS_MLP_CHAIN_MAX_C', '256'))
+
+
 def mlp_chain_eligible(x: torch.Tensor, C: int) -> bool:
     """The fused ConvNeXt MLP kernels (csrc/mlp_chain.hip) cover 16-bit activations with C % 8 == 0, C <= 512."""
-    return (not _NO_CHAIN and x.dtype in _MFMA_DTYPES and x.shape[3] == C
+    return (not _NO_CHAIN and x.dtype in _MFMA_DTYPES and x.shape[3] == C and C <= _CHAIN_MAX_C
             and lib.vkas_mlp_chain_image_elems(C) > 0)
 
 
@@ -803,7 +809,8 @@ class ConvNextLayer(Function):
         wdw = pack_dw_weight(dw_w, C, Cp, 0)
         y = new_act(B, H, W, Cp, x)
         dwb = pad_vector(dw_b, Cp)
-        _timed('dwconv7x7_fwd_kernel', x, 2.0 * 49 * M * C, M, Cp, 49,
+        dw_fwd_name = 'dwconv7x7_mfma_kernel' if x.dtype in _MFMA_DTYPES else 'dwconv7x7_fwd_kernel'  # rocprofv3 names
+        _timed(dw_fwd_name, x, 2.0 * 49 * M * C, M, Cp, 49,
                lambda: check(lib.vkas_dwconv7x7_fwd(_p(x), act_ld(x), _p(wdw), _p(dwb), None, 0, _p(y), Cp, B, H, W, Cp, dt,
                                                     st), 'dwconv7x7_fwd'), 2.0 * M * Cp * x.element_size())
         # LayerNorm
@@ -898,7 +905,8 @@ class ConvNextLayer(Function):
         gdw, gdb = gdwb[:49 * Cp], gdwb[49 * Cp:]
         nbytes = lib.vkas_dwconv7x7_wgrad_ws_bytes(B, H, W, Cp)
         ws = _ws(nbytes, dev)
-        _timed('dwconv7x7_wgrad_kernel', x, 2.0 * 49 * M * C, M, Cp, 49,
+        mfma = x.dtype in _MFMA_DTYPES
+        _timed('dwconv7x7_wgrad_mfma_kernel' if mfma else 'dwconv7x7_wgrad_kernel', x, 2.0 * 49 * M * C, M, Cp, 49,
                lambda: check(lib.vkas_dwconv7x7_wgrad(_p(x), act_ld(x), _p(dy), Cp, _p(gdw), _p(gdb), _p(ws), nbytes, B, H, W,
                                                       Cp, dt, st), 'dwconv7x7_wgrad'), 2.0 * M * Cp * x.element_size())
         sdw = grad_sink(dw_w)
@@ -913,7 +921,7 @@ class ConvNextLayer(Function):
         if ctx.needs_input_grad[0]:
             wflip = pack_dw_weight(dw_w, C, Cp, 1)
             dx = new_act(B, H, W, Cp, x)
-            _timed('dwconv7x7_fwd_kernel', x, 2.0 * 49 * M * C, M, Cp, 49,
+            _timed('dwconv7x7_mfma_kernel' if mfma else 'dwconv7x7_fwd_kernel', x, 2.0 * 49 * M * C, M, Cp, 49,
                    lambda: check(lib.vkas_dwconv7x7_fwd(_p(dy), Cp, _p(wflip), None, _p(dout), act_ld(dout), _p(dx), Cp, B, H,
                                                         W, Cp, dt, st), 'dwconv7x7_dgrad'), 3.0 * M * Cp * x.element_size())
         gdb_, dlg, dlb, db2_, dsc = deliver_small_grads([(dw_b, gdb[:C]), (ln_g, dlg), (ln_b, dlb), (b2, db2[:C]),
