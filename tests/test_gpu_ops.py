@@ -517,11 +517,19 @@ def test_loss_argument_rejection_on_gpu():
                                      z(B, ch, cw), (H, W), box, py, px, z(B, P, 2) if off is None else off, z(B, P, 4),
                                      z(B, P, 3))
     ok = torch.zeros(B, P, dtype=torch.long, device='cuda')
+    ops = ops_mod()
     float(precise(*args(ok, ok)))
+    ops.check_deferred(wait=True)
+    # label points outside the map: checked on the device, reported without stalling the step (at the next loss call or
+    # by check_deferred); the kernel itself clamps, so nothing is read out of bounds meanwhile
+    for bad in ((ok + H, ok), (ok, ok - 1)):
+        float(precise(*args(*bad)))
+        with pytest.raises(IndexError):
+            ops.check_deferred(wait=True)
+    precise(*args(ok, ok + W))
+    torch.cuda.synchronize()
     with pytest.raises(IndexError):
-        precise(*args(ok + H, ok))
-    with pytest.raises(IndexError):
-        precise(*args(ok, ok - 1))
+        precise(*args(ok, ok))  # the next call reports the previous batch
     with pytest.raises(ValueError):
         precise(*args(ok[:1], ok[:1]))
     with pytest.raises(ValueError):

@@ -1093,6 +1093,33 @@ class Softplus(Function):
         return dx
 
 
+_DEFERRED = []  # (pinned host tensor, event, message): device-side argument checks awaiting their verdict
+
+
+def _defer_check(min_margin: torch.Tensor, message: str):
+    """min_margin: 1-element int64 device tensor that is negative when the check failed."""
+    host = torch.empty((1,), dtype=min_margin.dtype, pin_memory=True)
+    host.copy_(min_margin, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _DEFERRED.append((host, ev, message))
+
+
+def check_deferred(wait: bool = False):
+    """Raise for any device-side argument check that has completed (all of them with wait=True) and failed."""
+    keep = []
+    for host, ev, message in _DEFERRED:
+        if wait:
+            ev.synchronize()
+        if ev.query():
+            if int(host[0]) < 0:
+                _DEFERRED.clear()
+                raise IndexError(message)
+        else:
+            keep.append((host, ev, message))
+    _DEFERRED[:] = keep
+
+
 def _check_loss_maps(who, preds, channels, gt_mask, gt_score, up, left):
     """Shape / device contract of the dense losses (loss_function/adaptive_scaling.py:67-86,213-231): every tensor on
     the GPU, predictions (B, c, H, W), targets (B, CH, CW) with the crop inside the map.  The kernels index with these
@@ -1162,12 +1189,13 @@ class PreciseLoss(Function):
             if tuple(t.shape) != (B, P, last):
                 raise ValueError(f'PreciseLoss: {name} must be ({B}, {P}, {last}), got {tuple(t.shape)}')
         if P > 0:
-            # the reference's advanced indexing raises on out-of-range label points (and wraps negative ones); a corrupt
-            # batch must not train on clamped pixels: one fused min/max + a single host read
-            lim = torch.stack([py.min(), py.max() - (H - 1), px.min(), px.max() - (W - 1)])
-            lo_y, hi_y, lo_x, hi_x = (int(v) for v in lim.tolist())
-            if lo_y < 0 or hi_y > 0 or lo_x < 0 or hi_x > 0:
-                raise IndexError(f'PreciseLoss: label points outside the {H}x{W} map')
+            # The reference's advanced indexing raises on out-of-range label points (and wraps negative ones); a corrupt
+            # batch must not train silently on the clamped pixels the kernel falls back to.  The range test runs on the
+            # device and its verdict travels to pinned host memory asynchronously: reading it here would stall the
+            # launch pipeline once per step, so it is examined at the NEXT loss call / check_deferred() (one step late).
+            check_deferred()
+            lim = torch.stack((py, (H - 1) - py, px, (W - 1) - px)).amin().reshape(1)
+            _defer_check(lim, f'PreciseLoss: label points outside the {H}x{W} map')
         sums = torch.empty((8,), dtype=torch.float64, device=prob.device)
         loss = torch.empty((), dtype=_FLOAT, device=prob.device)
         check(lib.vkas_precise_loss_fwd(_p(prob), _p(offset), _p(angle), _p(dist), _p(gt_score), _p(gt_mask), _p(py),
