@@ -196,6 +196,13 @@ def main():
                             merge_backbone=(args.schedule != 'merged'))
         o_ms = pass_ms(lambda: other(rough, precise, lr=8e-4), n=max(2, min(args.steps, 5)))
         per_pass['two_pass_ms_per_step' if args.schedule == 'merged' else 'merged_ms_per_step'] = round(o_ms, 2)
+        # The timed steps run the regression heads' backward on the label-point rows only (their gradient is zero
+        # elsewhere: ops.point_sparse, csrc/points.hip - same gradients, fewer products with zero).  The same step with
+        # that path switched off (every head's backward dense, as a framework without the loss's sparsity would run it):
+        ops._POINT_SPARSE = False
+        d_ms = pass_ms(lambda: step(rough, precise, lr=8e-4), n=max(2, min(args.steps, 5)))
+        ops._POINT_SPARSE = True
+        per_pass['dense_point_backward_ms_per_step'] = round(d_ms, 2)
 
     if rank == 0:
         print(f'[bench] {args.steps} steps in {elapsed:.3f} s on {world} GPU(s); host enqueue {enqueue:.3f} s; '
@@ -243,20 +250,22 @@ def main():
                     'algorithmic_bytes_per_launch': nb / max(summ[k]['launches'], 1),
                     'share_of_step_time': round(ms_ / (1000.0 * elapsed), 3)}
 
-        traffic = None
+        traffic, traffic_source = None, None
         pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         default_cfg = (args.size == 1024 and args.batch == 8 and args.dtype == 'bf16')
         if default_cfg and os.path.exists(pmc_path):  # per-launch HBM bytes from the rocprofv3 --pmc passes of this command
-            pmc = json.load(open(pmc_path)).get(dom)
-            if pmc:
+            pmc_all = json.load(open(pmc_path))
+            pmc = pmc_all.get(dom)
+            if pmc:  # measured by a separate rocprofv3 run of this command, not in this run: say which one
                 traffic = pmc['bytes_per_launch']
+                traffic_source = pmc_all.get('_meta', {}).get('source', 'profiles/pmc_traffic.json')
         is_gemm = lambda k: k.startswith(('gemm_', 'conv3x3_', 'mlp_chain_'))  # the depthwise / resize launches are timed too (HBM roofs)
         all_gemm_flops = sum(v['flops'] for k, v in summ.items() if is_gemm(k))
         all_gemm_ms = sum(v['ms'] for k, v in summ.items() if is_gemm(k))
         if summ:
             roof = stats(dom)
             roof = {'bound': roof['bound'], 'kernel': dom, 'achieved': roof['achieved'], 'peak': roof['peak'],
-                    'unit': roof['unit'], 'frac': roof['frac'], 'traffic': traffic,
+                    'unit': roof['unit'], 'frac': roof['frac'], 'traffic': traffic, 'traffic_source': traffic_source,
                     **{k: v for k, v in roof.items() if k not in ('bound', 'achieved', 'peak', 'unit', 'frac')},
                     'all_gemm_kernels': {'tflops': round(all_gemm_flops / (all_gemm_ms * 1e-3) / 1e12, 2) if all_gemm_ms > 0 else 0.0,
                                          'share_of_step_time': round(all_gemm_ms / (1000.0 * elapsed), 3)},
@@ -274,7 +283,9 @@ def main():
                                                            f'{args.size}x{args.size}, batch {args.batch} per pass per GPU '
                                                            f'(BASELINE.json configs[2]{"/[3]" if world > 1 else ""})',
                                                'global_batch': args.batch * world, 'images_per_step': images,
-                                               'parallelism': f'dp{world}', 'pass_schedule': args.schedule, 'per_pass': per_pass,
+                                               'parallelism': f'dp{world}', 'pass_schedule': args.schedule,
+                                               'label_point_backward': 'compact (B*P rows)' if ops._POINT_SPARSE else 'dense',
+                                               'per_pass': per_pass,
                                                'losses': [round(rl, 5), round(pl, 5)]},
                'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:

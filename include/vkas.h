@@ -283,6 +283,28 @@ int vkas_cross_entropy_fwd(const float* logits, const void* target, int hard, lo
 int vkas_cross_entropy_bwd(const float* logits, const void* target, int hard, long rows, int classes, const float* dloss,
                            float* dlogits, void* stream);
 
+/* ---- label-point backward of the regression heads: loss_function/adaptive_scaling.py:167-179,235-262 -------------------- */
+/* The precise loss reads the offset / angle / distance maps only at the (B,P) label points, so d(conv output) of those heads
+ * has B*P non-zero rows.  These calls compact them (csrc/points.hip) for vkas_head_tail_bwd and the GEMMs.
+ * prepare: py, px (B,P) int64 label points (clamped into the map like the loss does).  map (B*H*W int32 scratch) receives the
+ * owner point of every pixel (0x7f7f7f7f = none); pix (Mp >= B*P int32) = pixel index of point i when it owns its pixel,
+ * -1 - pixel for a duplicate of an earlier point, INT_MIN for the padding rows i >= B*P. */
+int vkas_points_prepare(const long* py, const long* px, int B, int P, int H, int W, int* map, int* pix, long Mp, void* stream);
+/* zs (Mp, Ns) = columns [c0, c0+Ns) of the z rows at the points; stats_s (n_heads, Mp, 2) / dproj_s (n_heads, Mp, 8) = the
+ * LayerNorm statistics (n_heads, M, 2) and the heads' d(proj) rows (M, 8) there.  Duplicates and padding rows get zero
+ * d(proj) (a pixel's gradient is taken once); padding rows are zero throughout.  16-bit activations. */
+int vkas_points_gather_rows(const void* z, long ldz, int c0, int Ns, const float* stats, const float* const* dproj,
+                            int n_heads, long M, const int* pix, long Mp, void* zs, float* stats_s, float* dproj_s,
+                            int dtype, void* stream);
+/* xs (Mp, 3, 3, Cp) = the zero-padded 3x3 neighbourhoods x[p + (ky-1, kx-1)] of the owner points (zeros elsewhere): the
+ * activation operand of a 1x1 weight-gradient GEMM whose result has the 3x3 convolution's packed (N, ky, kx, Cp) layout. */
+int vkas_points_gather_patches(const void* x, long ldx, int Cp, int B, int H, int W, const int* pix, long Mp, void* xs,
+                               int dtype, void* stream);
+/* D (Mp, 3, 3, Cp) fp32: D[i][ky][kx] is the input-gradient contribution of point i to pixel p_i + (ky-1, kx-1).  Adds them onto
+ * dx (B,H,W,Cp; ld lddx): every touched pixel is summed in fp32 by one workgroup and written once. */
+int vkas_points_scatter3x3(const float* D, const int* pix, const int* map, long Mp, int B, int H, int W, int Cp, void* dx,
+                           long lddx, int dtype, void* stream);
+
 /* ---- inference post-processing on the device: inferencing/adaptive_scaling.py:129-188,318-396 ------------------------ */
 /* mask_logit, height (B,1,H,W) fp32 -> out_mask (B,H,W) uint8 = sigmoid >= mask_thr, out_height (B,H,W) fp32 = height where
  * >= height_min else 0; both 0 on rows >= valid_h[b] / columns >= valid_w[b] (the divisible-by-32 padding, in feature

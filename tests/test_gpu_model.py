@@ -348,3 +348,79 @@ def test_config5_base_fp16_mixed_shape_inference():
     for o in const:  # constant image: interior (beyond every receptive-field border effect of the local ops) is flat
         core = o[0, 0, 300:-300, 200:-200]
         assert float((core - core.mean()).abs().max()) <= 2e-2 * max(1.0, float(core.abs().max()))
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+def test_point_sparse_head_backward_matches_dense(dtype):
+    """The offset / angle / distance heads receive gradient at the label points only (adaptive_scaling.py:235-262), so
+    their share of the head convolution's backward runs on B*P compact rows (csrc/points.hip).  Same gradients as the dense
+    backward - duplicate points, points on the border (zero padding of the 3x3 conv) and adjacent points (overlapping 3x3
+    neighbourhoods) included - for every parameter of the model."""
+    from vkit_ocr_model_adaptive_scaling_amd import ops
+    from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
+                                                           AdaptiveScalingNeckHeadType)
+    from vkit_ocr_model_adaptive_scaling_amd.loss_function import (
+        Box, AdaptiveScalingPreciseLossFunction, AdaptiveScalingPreciseLossFunctionConifg)
+    torch.manual_seed(5)
+    model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.TINY, AdaptiveScalingNeckHeadType.UPERNEXT),
+                            compute_dtype=dtype)
+    seed_module(model, 77, 0.05)
+    model.cuda().eval()
+    B, S, P = 2, 256, 24
+    H = W = S // 2
+    g = torch.Generator().manual_seed(3)
+    image = torch.randint(0, 256, (B, 3, S, S), generator=g).float().cuda()
+    py = torch.randint(0, H, (B, P), generator=g)
+    px = torch.randint(0, W, (B, P), generator=g)
+    py[0, :6] = torch.tensor([0, 0, H - 1, H - 1, 5, 5])       # corners ...
+    px[0, :6] = torch.tensor([0, W - 1, 0, W - 1, 0, W - 1])   # ... and edges
+    py[0, 6:9], px[0, 6:9] = 40, 41                            # one pixel three times
+    py[1, :4] = torch.tensor([60, 60, 61, 61])                 # a 2x2 block: every neighbourhood overlaps
+    px[1, :4] = torch.tensor([30, 31, 30, 31])
+    py[1, 4], px[1, 4] = py[0, 10], px[0, 10]                  # same coordinates in another image: not a duplicate
+    py, px = py.cuda(), px.cuda()
+    gt_score = torch.rand(B, H - 20, W - 20, generator=g).cuda()
+    gt_mask = (torch.rand(B, H - 20, W - 20, generator=g) > 0.3).float().cuda()
+    gt_off = (torch.rand(B, P, 2, generator=g) * 20 - 10).cuda()
+    gt_ang = torch.softmax(torch.randn(B, P, 4, generator=g), -1).cuda()
+    gt_dist = (torch.rand(B, P, 3, generator=g) * 10).cuda()
+    box = Box(up=10, down=H - 11, left=10, right=W - 11)
+    loss_fn = AdaptiveScalingPreciseLossFunction(AdaptiveScalingPreciseLossFunctionConifg())
+
+    # fp16 gradients of a mean over 32K pixels underflow without loss scaling (dense path and compact path alike): scale
+    # as torch.cuda.amp.GradScaler would
+    scale = 1024.0 if dtype == torch.float16 else 1.0
+
+    def run(sparse):
+        old = ops._POINT_SPARSE
+        ops._POINT_SPARSE = sparse
+        try:
+            model.zero_grad(set_to_none=True)
+            outs = model.forward_precise(image)
+            loss = loss_fn(None, *outs, gt_score, gt_mask, (H, W), box, py, px, gt_off, gt_ang, gt_dist)
+            (loss * scale).backward()
+            torch.cuda.synchronize()
+            return float(loss), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        finally:
+            ops._POINT_SPARSE = old
+
+    l_dense, g_dense = run(False)
+    l_sparse, g_sparse = run(True)
+    assert l_dense == l_sparse
+    assert set(g_dense) == set(g_sparse) and len(g_dense) > 150
+    # the precise heads' own parameters see identical operands up to the summation order
+    heads = {n: rel_err(g_sparse[n], g_dense[n]) for n in g_dense if n.startswith('precise_char_') and 'head' in n}
+    print('heads: worst sparse vs dense', max(heads.values()))
+    assert heads and max(heads.values()) < 1e-5, heads
+    # Below the heads the two runs are two valid 16-bit roundings of the same dx (one rounding of the full sum vs the dense
+    # heads' rounded sum plus the fp32 point terms), and that difference is amplified on the way down the backbone: judge
+    # both against the fp32 evaluation of the same model - the compact path must be as close to it as the dense one.
+    model.set_compute_dtype(torch.float32)
+    _, g_ref = run(False)
+    model.set_compute_dtype(dtype)
+    e_s = {n: rel_err(g_sparse[n], g_ref[n]) for n in g_ref}
+    e_d = {n: rel_err(g_dense[n], g_ref[n]) for n in g_ref}
+    print('vs fp32: worst sparse', max(e_s.values()), 'worst dense', max(e_d.values()))
+    assert max(e_s.values()) < GRAD_TOL[dtype], max(e_s, key=e_s.get)
+    worse = {n: (e_s[n], e_d[n]) for n in g_ref if e_s[n] > 1.5 * e_d[n] + 2e-3}
+    assert not worse, worse

@@ -737,34 +737,95 @@ class HeadsFused(Function):
         B, H, W, Cp = x.shape
         Nt = z.shape[3]
         M = B * H * W
-        dev = x.device
-        dz = new_act(B, H, W, Nt, x)
-        dparams = torch.empty((n_heads, 6 * pw + 8), dtype=_FLOAT, device=dev)
-        nbytes = lib.vkas_head_tail_bwd_ws_bytes(M, pw)
-        ws_buf = _ws(nbytes, dev)
-        head = _lib.HeadDesc()
-        head.n_heads, head.pw = n_heads, pw
-        off = 0
-        dps = []
-        ptrs = (ctypes.c_void_p * 4)()
-        for h in range(n_heads):
-            head.n0[h], head.np[h], head.c[h], head.oc[h] = off, nps[h], cs[h], ocs[h]
-            off += nps[h]
-            dp = dprojs[h]
-            dp = torch.zeros((B, H, W, 8), dtype=_FLOAT, device=dev) if dp is None else dp.contiguous().float()
-            dps.append(dp)
-            ptrs[h] = dp.data_ptr()
-        head.params, head.stats, head.proj = hp.data_ptr(), stats.data_ptr(), None
-        _timed('head_tail_bwd_kernel', x, 0.0, M, Nt, 0,
-               lambda: check(lib.vkas_head_tail_bwd(_p(z), Nt, ctypes.byref(head), ptrs, _p(dz), Nt, _p(dparams), _p(ws_buf),
-                                                    nbytes, M, _dt(x), _stream()), 'head_tail_bwd'),
-               float(M) * (2 * Nt * x.element_size() + n_heads * 40))
-        geom = _geom(B, H, W, H, W, Cp, act_ld(x), 3, 3, 1, 1)
-        gwp, gbp = conv_wgrad(x, geom, dz, Nt, nk=(sum(cs), C * 9), with_bias=True)
         K = 9 * Cp
-        gws, gbs, off = [], [], 0
+        dev = x.device
+        PS = 6 * pw + 8
+        offs = [sum(nps[:h]) for h in range(n_heads + 1)]
+        dparams = torch.empty((n_heads, PS), dtype=_FLOAT, device=dev)
+        gbuf = torch.zeros((Nt * K + Nt,), dtype=_FLOAT, device=dev)  # packed weight gradient | bias gradient, one memset
+        gwp, gbp = gbuf[:Nt * K], gbuf[Nt * K:]
+        dps = []
         for h in range(n_heads):
-            gslice = gwp[off * K:(off + nps[h]) * K]
+            dp = dprojs[h]
+            dps.append(torch.zeros((B, H, W, 8), dtype=_FLOAT, device=dev) if dp is None else dp.contiguous().float())
+
+        def tail_bwd(h0, h1, z_ptr, ldz, stats_ptr, dp_ptrs, rows, dz):
+            """vkas_head_tail_bwd for heads [h0, h1) whose z columns start at z_ptr: dz (rows, width) and dparams[h0:h1]."""
+            head = _lib.HeadDesc()
+            head.n_heads, head.pw = h1 - h0, pw
+            ptrs = (ctypes.c_void_p * 4)()
+            for j, h in enumerate(range(h0, h1)):
+                head.n0[j], head.np[j], head.c[j], head.oc[j] = offs[h] - offs[h0], nps[h], cs[h], ocs[h]
+                ptrs[j] = dp_ptrs[j]
+            head.params, head.stats, head.proj = hp.data_ptr() + h0 * PS * 4, stats_ptr, None
+            nbytes = lib.vkas_head_tail_bwd_ws_bytes(rows, pw)
+            ws_buf = _ws(nbytes, dev)
+            width = offs[h1] - offs[h0]
+            _timed('head_tail_bwd_kernel', x, 0.0, rows, width, 0,
+                   lambda: check(lib.vkas_head_tail_bwd(ctypes.c_void_p(z_ptr), ldz, ctypes.byref(head), ptrs, _p(dz), width,
+                                                        ctypes.c_void_p(dparams.data_ptr() + h0 * PS * 4), _p(ws_buf), nbytes,
+                                                        rows, _dt(x), _stream()), 'head_tail_bwd'),
+                   float(rows) * (2 * width * x.element_size() + (h1 - h0) * 40))
+
+        # Heads whose gradient arrives from a label-point loss (PreciseLoss marks it, see point_sparse) have B*P non-zero
+        # rows: they take the compact path below and only the remaining heads pay for the dense backward.
+        sp = _point_sparse_run(dprojs, B, H, W) if _POINT_SPARSE else None
+        d0, d1 = (0, n_heads) if sp is None else ((0, sp[0]) if sp[0] > 0 else (sp[1], n_heads))
+        es = x.element_size()
+        dx = new_act(B, H, W, Cp, x) if ctx.needs_input_grad[0] else None
+        if d1 > d0:
+            Nd = offs[d1] - offs[d0]
+            dz = new_act(B, H, W, Nd, x)
+            tail_bwd(d0, d1, z.data_ptr() + offs[d0] * es, Nt, stats.data_ptr() + d0 * M * 8,
+                     [dps[h].data_ptr() for h in range(d0, d1)], M, dz)
+            geom = _geom(B, H, W, H, W, Cp, act_ld(x), 3, 3, 1, 1)
+            conv_wgrad(x, geom, dz, Nd, nk=(sum(cs[d0:d1]), C * 9), with_bias=True,
+                       gw_into=gwp[offs[d0] * K:offs[d1] * K], gb_into=gbp[offs[d0]:offs[d1]])
+            if dx is not None:
+                Bt = pack_head_weights(ws[d0:d1], nps[d0:d1], Cp, 1, x.dtype)
+                g2 = _geom(B, H, W, H, W, Nd, Nd, 3, 3, 1, 1)
+                conv_gemm(dz, g2, Bt, Cp, dx, _lib.EPI_NONE, nk=(C, sum(cs[d0:d1]) * 9))
+            del dz
+        elif dx is not None:
+            dx.zero_()
+        if sp is not None:
+            s0, s1, py, px = sp
+            Ns = offs[s1] - offs[s0]
+            P = py.shape[1]
+            Mp = -(-(B * P) // 64) * 64
+            scratch = torch.empty((M + Mp,), dtype=torch.int32, device=dev)
+            pmap, pix = scratch[:M], scratch[M:]
+            check(lib.vkas_points_prepare(_p(py), _p(px), B, P, H, W, _p(pmap), _p(pix), Mp, _stream()), 'points_prepare')
+            zs = new_act(1, 1, Mp, Ns, x)
+            fbuf = torch.empty(((s1 - s0) * Mp * 10,), dtype=_FLOAT, device=dev)
+            stats_s, dproj_s = fbuf[:(s1 - s0) * Mp * 2], fbuf[(s1 - s0) * Mp * 2:]
+            ptrs = (ctypes.c_void_p * 4)(*[dps[h].data_ptr() for h in range(s0, s1)])
+            check(lib.vkas_points_gather_rows(_p(z), Nt, offs[s0], Ns, ctypes.c_void_p(stats.data_ptr() + s0 * M * 8), ptrs,
+                                              s1 - s0, M, _p(pix), Mp, _p(zs), _p(stats_s), _p(dproj_s), _dt(x), _stream()),
+                  'points_gather_rows')
+            dzs = new_act(1, 1, Mp, Ns, x)
+            tail_bwd(s0, s1, zs.data_ptr(), Ns, stats_s.data_ptr(),
+                     [dproj_s.data_ptr() + j * Mp * 32 for j in range(s1 - s0)], Mp, dzs)
+            # weight / bias gradient: (Ns x Mp) . (Mp x 9 Cp) on the gathered 3x3 patches
+            xs = new_act(1, 1, Mp, K, x)
+            check(lib.vkas_points_gather_patches(_p(x), act_ld(x), Cp, B, H, W, _p(pix), Mp, _p(xs), _dt(x), _stream()),
+                  'points_gather_patches')
+            g1 = _geom(1, 1, Mp, 1, Mp, K, K, 1, 1, 1, 0)
+            conv_wgrad(xs, g1, dzs, Ns, nk=(sum(cs[s0:s1]), C * 9), with_bias=True,
+                       gw_into=gwp[offs[s0] * K:offs[s1] * K], gb_into=gbp[offs[s0]:offs[s1]])
+            if dx is not None:
+                # input gradient: D (Mp x 9 Cp, fp32) = dz_s . W with W (Ns x 9 Cp) the rows of the forward weight image -
+                # the reduction runs over W's ROWS, i.e. this is the weight-gradient GEMM shape with dz_s^T as the "dy"
+                # operand (fp32 result, no 16-bit rounding of the per-tap terms) - then summed per touched pixel onto dx
+                Wf = pack_head_weights(ws, nps, Cp, 0, x.dtype)[offs[s0] * K:offs[s1] * K].view(1, 1, Ns, K)
+                dzt = dzs.view(Mp, Ns).t().contiguous().view(1, 1, Ns, Mp)
+                g3 = _geom(1, 1, Ns, 1, Ns, K, K, 1, 1, 1, 0)
+                D = conv_wgrad(Wf, g3, dzt, Mp, nk=(B * P, C * 9))
+                check(lib.vkas_points_scatter3x3(_p(D), _p(pix), _p(pmap), Mp, B, H, W, Cp, _p(dx), act_ld(dx), _dt(x),
+                                                 _stream()), 'points_scatter3x3')
+        gws, gbs = [], []
+        for h in range(n_heads):
+            gslice = gwp[offs[h] * K:offs[h + 1] * K]
             sw = grad_sink(ws[h])
             if sw is not None:  # straight into the flat gradient view
                 unpack_wgrad(gslice, (cs[h], C, 3, 3), nps[h], Cp, into=ws[h].grad)
@@ -772,20 +833,54 @@ class HeadsFused(Function):
                 gws.append(None)
             else:
                 gws.append(unpack_wgrad(gslice, (cs[h], C, 3, 3), nps[h], Cp))
-            gbs.append(gbp[off:off + cs[h]])
-            off += nps[h]
-        dx = None
-        if ctx.needs_input_grad[0]:
-            Bt = pack_head_weights(ws, nps, Cp, 1, x.dtype)
-            dx = new_act(B, H, W, Cp, x)
-            g2 = _geom(B, H, W, H, W, Nt, Nt, 3, 3, 1, 1)
-            conv_gemm(dz, g2, Bt, Cp, dx, _lib.EPI_NONE, nk=(C, sum(cs) * 9))
+            gbs.append(gbp[offs[h]:offs[h] + cs[h]])
         grads = []
         for h in range(n_heads):
             d = dparams[h]
             grads.extend([gws[h], gbs[h], d[:cs[h]], d[pw:pw + cs[h]], d[2 * pw:6 * pw].view(4, pw)[:ocs[h], :cs[h]],
                           d[6 * pw:6 * pw + ocs[h]]])
         return (dx, None, *grads)
+
+
+_POINT_SPARSE = os.environ.get('VKAS_POINT_SPARSE_BWD', '1') != '0'
+
+
+def point_sparse(grad: torch.Tensor, py: torch.Tensor, px: torch.Tensor) -> torch.Tensor:
+    """Mark ``grad`` - a dense (B, C, H, W) or (B, H, W, C) gradient - as zero everywhere but at the label points (py, px)
+    of its images.  The mark is a Python attribute of this very tensor object: autograd hands the same object to the next
+    backward function when the gradient has a single consumer, and anything that builds a new tensor (a sum with another
+    gradient, a view, a cast) drops the mark, so a consumer that finds it can rely on it.  Only functions that keep the
+    zero pattern (per-pixel maps) may pass it on (``pass_point_sparse``)."""
+    grad._vkas_points = (py, px)
+    return grad
+
+
+def pass_point_sparse(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    pts = getattr(src, '_vkas_points', None)
+    if pts is not None:
+        dst._vkas_points = pts
+    return dst
+
+
+def _point_sparse_run(dprojs, B, H, W):
+    """(h0, h1, py, px) when the heads [h0, h1) - a prefix or a suffix of the heads, so that the others stay one contiguous
+    run of z columns - all carry the mark of the SAME label points and the compact path pays (points << pixels)."""
+    marks = [getattr(d, '_vkas_points', None) if d is not None else None for d in dprojs]
+    idx = [h for h, m in enumerate(marks) if m is not None]
+    if not idx:
+        return None
+    h0, h1 = idx[0], idx[-1] + 1
+    py, px = marks[h0]
+    if idx != list(range(h0, h1)) or (h0 > 0 and h1 < len(dprojs)):
+        return None
+    if any(m[0] is not py or m[1] is not px for m in (marks[h] for h in idx)):
+        return None
+    if (py.dim() != 2 or py.shape != px.shape or py.shape[0] != B or py.dtype != torch.int64 or px.dtype != torch.int64
+            or not py.is_cuda or not py.is_contiguous() or not px.is_contiguous() or py.shape[1] == 0):
+        return None
+    if py.numel() * 16 > B * H * W:
+        return None
+    return h0, h1, py, px
 
 
 class ConvNextLayer(Function):
@@ -1063,13 +1158,14 @@ class ToNchw(Function):
     @staticmethod
     def backward(ctx, g):
         Cp, dtype = ctx.cfg
+        mark = g
         g = g.contiguous().float()
         B, C, H, W = g.shape
         out = torch.empty((B, H, W, Cp), dtype=dtype, device=g.device)
         check(lib.vkas_nchw_f32_to_nhwc(_p(g), _p(out), Cp, B, H, W, C, Cp,
                                         _dtc(dtype), _stream()),
               'nchw_f32_to_nhwc')
-        return out, None
+        return pass_point_sparse(mark, out), None  # a permutation of the pixels' channels
 
 
 class Softplus(Function):
@@ -1087,10 +1183,11 @@ class Softplus(Function):
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
+        mark = dy
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         check(lib.vkas_softplus_bwd(_p(x), _p(dy), _p(dx), x.numel(), _stream()), 'softplus_bwd')
-        return dx
+        return pass_point_sparse(mark, dx)  # elementwise: zero gradient stays zero
 
 
 _DEFERRED = []  # (pinned host tensor, event, message): device-side argument checks awaiting their verdict
@@ -1218,6 +1315,10 @@ class PreciseLoss(Function):
                                         _p(px), _p(gt_off), _p(gt_ang), _p(gt_dist), B, H, W, up, left, CH, CW, P,
                                         ctypes.byref(cfg), _p(sums), _p(dloss), _p(dp), _p(do), _p(da), _p(dd),
                                         _stream()), 'precise_loss_bwd')
+        # offset / angle / distance are read at the label points only (adaptive_scaling.py:235-262): their gradients are
+        # zero elsewhere, which the heads' backward exploits
+        for g in (do, da, dd):
+            point_sparse(g, py, px)
         return (dp, do, da, dd) + (None,) * 10
 
 
