@@ -50,6 +50,17 @@ constexpr int BK = 64;
 #endif
 constexpr int ABL = VKAS_ABL;
 
+// Phase timestamps of gemm_nt_mfma_kernel for profiles/trace_nt.py (-DVKAS_TRACE builds only, never shipped): 8 slots per
+// workgroup - s_memtime at entry, after the prologue barrier, after the K loop, after the epilogue (stores issued), after
+// the stores were acknowledged; slot 6 = HW_ID, slot 7 = XCC_ID.
+#if defined(VKAS_TRACE) && !defined(VKAS_MFMA_F16)
+__device__ unsigned long long vkas_trace_buf[65536 * 8];
+#define VKAS_TR(slot)                                                                                      \
+  if (threadIdx.x == 0 && blockIdx.x < 65536) vkas_trace_buf[blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter()
+#else
+#define VKAS_TR(slot)
+#endif
+
 __device__ __forceinline__ int swz_off(int row, int chunk) {  // element offset inside a [rows][64] bf16 tile
   return row * BK + ((chunk ^ (row & 7)) << 3);
 }
@@ -233,6 +244,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const elem_t*
   // halo rows) then hit the same L2 instead of re-reading A from HBM.  Pure speed choice, any placement is correct.
   constexpr bool head_mode = HEAD;  // N tiles = heads (each <= BN wide, at its own column offset)
   const unsigned ntile_n = head_mode ? (unsigned)e.head.n_heads : (unsigned)((Np + BN - 1) / BN);
+  VKAS_TR(0);
   const unsigned total = gridDim.x;
   const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const unsigned q8 = total >> 3, r8 = total & 7u;
@@ -356,6 +368,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const elem_t*
   store_tile(0);
   if (nk > 1) load_tile();  // registers now hold tile 1
   __syncthreads();
+  VKAS_TR(1);
 
   const int frow = lane & 15;
   const int fchunk = lane >> 4;
@@ -425,7 +438,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const elem_t*
   }
 
   static_assert(TM * 16 * (BN + 4) * 4 <= 2 * (BM + BN) * BK * 2, "epilogue staging must fit the tile buffers");
+  VKAS_TR(2);
   nt_epilogue<WM, WN, TM, TN, HEAD>(acc, reinterpret_cast<float*>(lds), e, tile_n, m0, M, n0, n_end, tid);
+  VKAS_TR(3);
+#if defined(VKAS_TRACE) && !defined(VKAS_MFMA_F16)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  VKAS_TR(4);
+  if (threadIdx.x == 0 && blockIdx.x < 65536) {
+    vkas_trace_buf[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+    vkas_trace_buf[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1279,6 +1302,11 @@ bool vkas_tn_slab_eligible(const vkas_conv_geom* g, int Np, long lddy) {
   return !no_slab && row_aligned_3x3(g, 64) && M >= 65536 && Np >= 112 && g->Cp >= 128 && x_bytes < 0xFFFFFFF0L &&
          dy_bytes < 0xFFFFFFF0L;
 }
+#ifdef VKAS_TRACE
+extern "C" int vkas_trace_read(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(vkas_trace_buf), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
 bool vkas_tn_slab_n112(int Np) { return vkas_cdiv(Np, 112) * 112 < vkas_cdiv(Np, 128) * 128; }  // 112-wide tiles pad less
 
 #endif  // VKAS_MFMA_F16
