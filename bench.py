@@ -100,6 +100,9 @@ def main():
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-per-pass', action='store_true',
+                    help='skip the single-pass / other-schedule / dense-backward side measurements (profiling runs: the '
+                         'kernel statistics then cover warmup + timed steps only)')
     ap.add_argument('--detail', action='store_true', help='per-shape GEMM timing table on stderr')
     ap.add_argument('--schedule', choices=('merged', 'two-pass'), default='merged',
                     help='merged: one backbone pass over the rough + precise batches and one backward of the summed loss '
@@ -176,7 +179,7 @@ def main():
     # also the single-pass rates (forward + loss + backward of one batch of `batch` images, no optimizer),
     # so that either reading of "batch 8" is covered.  Outside the timed region; one rank only.
     per_pass = None
-    if world == 1:
+    if world == 1 and not args.no_per_pass:
         def pass_ms(run, n=3):
             run()
             torch.cuda.synchronize()

@@ -52,17 +52,19 @@ assert raw.vkas_trace_read(ctypes.c_void_p(buf.ctypes.data), ctypes.c_size_t(buf
 t = buf.reshape(-1, 8)
 nb = int((t[:, 0] != 0).sum())
 t = t[:nb].astype(np.int64)
+if os.environ.get('VKAS_NT_NOSTREAM') is None and M >= 16384:
+    print(f'  (streaming kernel: per workgroup, summed over its {int(np.median(t[:, 5]))} tiles: K loop = all K loops, epilogue = all epilogues)')
 print(f'M={M} N={N} K={K} mode={mode}: {nb} workgroups, launch {s.elapsed_time(e) * 1e3:.1f} us')
 xcc = t[:, 7] & 0xf
 # the counters of different XCDs are not aligned: calibrate the tick on the XCD with the longest first start -> last end
 # (event time of the launch ~ that span) and never compare timestamps across XCDs
 span = max(float(t[xcc == c][:, 4].max() - t[xcc == c][:, 0].min()) for c in np.unique(xcc))
-tick = s.elapsed_time(e) * 1e3 / span
-print(f'  {1.0 / tick:.1f} s_memtime ticks per us (calibrated on the launch)')
+tick = 1.0 / 2100.0  # s_memtime counts shader clocks (~2.1 GHz under load); spans across CUs are not comparable
+
 names = ['prologue (first tiles landed)', 'K loop', 'epilogue (stores issued)', 'stores acknowledged']
 for i, n in enumerate(names):
     d = (t[:, i + 1] - t[:, i]) * tick
-    print(f'  {n:32s} median {np.median(d):7.2f} us   p10 {np.percentile(d, 10):7.2f}   p90 {np.percentile(d, 90):7.2f}')
+    print(f'  {n:32s} median {np.median(d):7.2f} us ({np.median(d) / tick:8.0f} cycles)   p10 {np.percentile(d, 10):7.2f}   p90 {np.percentile(d, 90):7.2f}')
 life = (t[:, 4] - t[:, 0]) * tick
 print(f'  workgroup lifetime               median {np.median(life):7.2f} us')
 # successive workgroups of one CU: (xcc, se, sh, cu) from XCC_ID / HW_ID
@@ -74,5 +76,7 @@ for c in np.unique(cu):
     rows = rows[np.argsort(rows[:, 0])]
     per_cu.append(len(rows))
     gaps.extend(((rows[1:, 0] - rows[:-1, 4]) * tick).tolist())
+if not gaps:
+    gaps = [0.0]
 print(f'  {len(np.unique(cu))} CUs, workgroups per CU {min(per_cu)}..{max(per_cu)}; gap between a workgroup\'s end and the next start '
       f'on its CU: median {np.median(gaps):.2f} us, p90 {np.percentile(gaps, 90):.2f} us')
