@@ -305,6 +305,21 @@ int vkas_points_gather_patches(const void* x, long ldx, int Cp, int B, int H, in
 int vkas_points_scatter3x3(const float* D, const int* pix, const int* map, long Mp, int B, int H, int W, int Cp, void* dx,
                            long lddx, int dtype, void* stream);
 
+/* ---- all packed operands of a step in one launch ------------------------------------------------------------------- */
+/* One entry per packed image: kind 0 = vkas_pack_conv_weight(_slice) (mode, n_off, Nt, dtype as there; a plain weight has
+ * n_off = 0, Nt = Np), kind 1 = vkas_pack_dw_weight (mode = flip; N, KH, KW, Np, n_off, Nt, dtype unused).  total =
+ * elements of the image. */
+typedef struct {
+  const float* w;
+  void* out;
+  long total;
+  int kind, N, C, KH, KW, Np, Cp, mode, n_off, Nt, dtype;
+} vkas_pack_desc;
+/* descs (count entries) and block_start (count + 1 ints: first workgroup of every entry, 2048 elements per workgroup;
+ * block_start[count] = total_blocks) live in DEVICE memory and stay valid until the launch has run: the table of a model is
+ * built once and re-used every step (the parameters and their images keep their addresses). */
+int vkas_pack_many(const vkas_pack_desc* descs, const int* block_start, int count, int total_blocks, void* stream);
+
 /* ---- inference post-processing on the device: inferencing/adaptive_scaling.py:129-188,318-396 ------------------------ */
 /* mask_logit, height (B,1,H,W) fp32 -> out_mask (B,H,W) uint8 = sigmoid >= mask_thr, out_height (B,H,W) fp32 = height where
  * >= height_min else 0; both 0 on rows >= valid_h[b] / columns >= valid_w[b] (the divisible-by-32 padding, in feature

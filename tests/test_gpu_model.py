@@ -424,3 +424,43 @@ def test_point_sparse_head_backward_matches_dense(dtype):
     assert max(e_s.values()) < GRAD_TOL[dtype], max(e_s, key=e_s.get)
     worse = {n: (e_s[n], e_d[n]) for n in g_ref if e_s[n] > 1.5 * e_d[n] + 2e-3}
     assert not worse, worse
+
+
+def test_batched_repack_matches_lazy_packs():
+    """ops.refresh_packed_params() (one vkas_pack_many launch after the optimizer step) leaves exactly the images the
+    per-parameter pack launches would build from the updated parameters, for every recorded recipe (conv weights in the
+    forward / dgrad layouts, depthwise weights, the heads' side-by-side slices)."""
+    from vkit_ocr_model_adaptive_scaling_amd import ops
+    from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
+                                                           AdaptiveScalingNeckHeadType)
+    from vkit_ocr_model_adaptive_scaling_amd.training import FlatBuffers
+    torch.manual_seed(9)
+    model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.TINY, AdaptiveScalingNeckHeadType.UPERNEXT),
+                            compute_dtype=torch.bfloat16)
+    seed_module(model, 5, 0.05)
+    model.cuda().train()
+    fb = FlatBuffers(model.named_parameters())
+    x = torch.randint(0, 256, (2, 3, 256, 256), device='cuda').float()
+
+    def step():
+        outs = model.forward_rough(x) + model.forward_precise(x)
+        sum(o.float().square().mean() for o in outs).backward()
+
+    ops.invalidate_packed_params()
+    step()
+    n_plan = len(ops._PACK_PLAN)
+    assert n_plan > 80, n_plan                      # conv (two layouts), depthwise (two flips) and head recipes
+    fb.flat_param.add_(torch.randn_like(fb.flat_param) * 0.01)   # what the optimizer does: in place, behind the counters
+    ops.refresh_packed_params()
+    assert len(ops._PACK_PLAN) == n_plan
+    batched = {k: ops._PACK_CACHE[k][2].clone() for k in ops._PACK_PLAN}
+    ops.invalidate_packed_params()
+    step()                                           # lazy per-parameter packs of the same (updated) parameters
+    assert set(ops._PACK_PLAN) == set(batched)
+    for k, img in batched.items():
+        assert torch.equal(ops._PACK_CACHE[k][2], img), k[1]
+    # and a second refresh re-uses the uploaded table
+    table = ops._PACK_TABLE[0][1].data_ptr()
+    ops.refresh_packed_params()
+    ops.refresh_packed_params()
+    assert ops._PACK_TABLE[0][1].data_ptr() == table

@@ -34,6 +34,12 @@ class Epilogue(Structure):
                 ('patch_Ws', c_int), ('patch_Cp', c_int), ('head', HeadDesc)]
 
 
+class PackDesc(Structure):
+    _fields_ = [('w', c_void_p), ('out', c_void_p), ('total', c_long), ('kind', c_int), ('N', c_int), ('C', c_int),
+                ('KH', c_int), ('KW', c_int), ('Np', c_int), ('Cp', c_int), ('mode', c_int), ('n_off', c_int),
+                ('Nt', c_int), ('dtype', c_int)]
+
+
 class RoughLossCfg(Structure):
     _fields_ = [('focal_factor', c_float), ('dice_factor', c_float), ('l1_factor', c_float), ('score_min', c_float),
                 ('height_min', c_float), ('focal_alpha', c_float), ('focal_gamma', c_float), ('out_scale', c_float)]
@@ -117,6 +123,7 @@ _SIGS = {
     'vkas_points_gather_rows': (c_int, [_P, c_long, c_int, c_int, _P, _P, c_int, c_long, _P, c_long, _P, _P, _P, c_int, _P]),
     'vkas_points_gather_patches': (c_int, [_P, c_long, c_int, c_int, c_int, c_int, _P, c_long, _P, c_int, _P]),
     'vkas_points_scatter3x3': (c_int, [_P, _P, _P, c_long, c_int, c_int, c_int, c_int, _P, c_long, c_int, _P]),
+    'vkas_pack_many': (c_int, [_P, _P, c_int, c_int, _P]),
     'vkas_rough_postprocess': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P]),
     'vkas_precise_postprocess': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     'vkas_l2norm_sq': (c_int, [_P, c_long, _P, _P]),

@@ -6,34 +6,92 @@ namespace {
 
 // n_off / Nt: the weight fills output channels [n_off, n_off + Np) of an operand with Nt output channels in total (several
 // convolutions that share their input packed side by side: the heads of a pass); n_off = 0, Nt = Np is the plain case.
+// element i of a packed conv weight: value and destination index
+__device__ __forceinline__ float pack_conv_elem(const float* __restrict__ w, long i, int N, int C, int KH, int KW, int Np, int Cp,
+                                                int mode, int n_off, int Nt, long& o) {
+  int n, c, ky, kx;
+  long r = i;
+  o = i;
+  if (mode == 0) {  // [n][ky][kx][c]
+    c = (int)(r % Cp); r /= Cp;
+    kx = (int)(r % KW); r /= KW;
+    ky = (int)(r % KH); r /= KH;
+    n = (int)r;
+    o = i + (long)n_off * KH * KW * Cp;
+  } else if (mode == 1) {  // [c][ky'][kx'][n], taps rotated by 180 degrees
+    n = (int)(r % Np); r /= Np;
+    o = r * Nt + n_off + n;
+    kx = KW - 1 - (int)(r % KW); r /= KW;
+    ky = KH - 1 - (int)(r % KH); r /= KH;
+    c = (int)r;
+  } else {  // [(ky,kx,c)][n]
+    n = (int)(r % Np); r /= Np;
+    c = (int)(r % Cp); r /= Cp;
+    kx = (int)(r % KW); r /= KW;
+    ky = (int)r;
+  }
+  return (n < N && c < C) ? w[(((long)n * C + c) * KH + ky) * KW + kx] : 0.f;
+}
+
+// element i of a packed depthwise weight (see pack_dw_weight_kernel); false beyond the image
+__device__ __forceinline__ bool pack_dw_elem(const float* __restrict__ w, int i, int C, int Cp, int flip, float& v) {
+  if (i < 49 * Cp) {
+    const int tap = i / Cp, c = i - tap * Cp;
+    const int src_tap = flip ? 48 - tap : tap;
+    v = c < C ? w[(long)c * 49 + src_tap] : 0.f;
+    return true;
+  }
+  const int j = i - 49 * Cp;
+  if (j >= (Cp / 2) * 112) return false;
+  const int p = j / 112, r = j - p * 112;
+  const int ky = r >> 4, e = r & 15;
+  const int kx = e >> 1, c = 2 * p + (e & 1);
+  v = 0.f;
+  if (kx < 7 && c < C) {
+    const int tap = ky * 7 + kx;
+    v = w[(long)c * 49 + (flip ? 48 - tap : tap)];
+  }
+  return true;
+}
+
+// Every packed operand of a training step in ONE launch (vkas_pack_many): the optimizer changes all parameters at once, so
+// their GEMM / depthwise images are rebuilt together instead of by ~150 launches of a few microseconds each.  Workgroup b
+// serves 2048 elements of the entry e with block_start[e] <= b < block_start[e+1] (binary search in the table).
+constexpr int PM_ELEMS = 2048;
+__global__ __launch_bounds__(256) void pack_many_kernel(const vkas_pack_desc* __restrict__ descs,
+                                                        const int* __restrict__ block_start, int count) {
+  int lo = 0, hi = count;  // block_start[lo] <= blockIdx.x < block_start[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)blockIdx.x >= block_start[mid]) lo = mid;
+    else hi = mid;
+  }
+  const vkas_pack_desc d = descs[lo];
+  const long base = (long)((int)blockIdx.x - block_start[lo]) * PM_ELEMS;
+#pragma unroll
+  for (int u = 0; u < PM_ELEMS / 256; ++u) {
+    const long i = base + u * 256 + threadIdx.x;
+    if (i >= d.total) return;
+    if (d.kind == 1) {
+      float v;
+      if (pack_dw_elem(d.w, (int)i, d.C, d.Cp, d.mode, v)) reinterpret_cast<float*>(d.out)[i] = v;
+    } else {
+      long o;
+      const float v = pack_conv_elem(d.w, i, d.N, d.C, d.KH, d.KW, d.Np, d.Cp, d.mode, d.n_off, d.Nt, o);
+      if (d.dtype == VKAS_BF16) reinterpret_cast<bf16_t*>(d.out)[o] = from_f32<bf16_t>(v);
+      else if (d.dtype == VKAS_F16) reinterpret_cast<f16_t*>(d.out)[o] = from_f32<f16_t>(v);
+      else reinterpret_cast<float*>(d.out)[o] = v;
+    }
+  }
+}
+
 template <typename T>
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int N, int C, int KH, int KW,
                                         int Np, int Cp, int mode, long total, int n_off, int Nt) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int n, c, ky, kx;
-    long r = i;
-    long o = i;
-    if (mode == 0) {  // [n][ky][kx][c]
-      c = (int)(r % Cp); r /= Cp;
-      kx = (int)(r % KW); r /= KW;
-      ky = (int)(r % KH); r /= KH;
-      n = (int)r;
-      o = i + (long)n_off * KH * KW * Cp;
-    } else if (mode == 1) {  // [c][ky'][kx'][n], taps rotated by 180 degrees
-      n = (int)(r % Np); r /= Np;
-      o = r * Nt + n_off + n;
-      kx = KW - 1 - (int)(r % KW); r /= KW;
-      ky = KH - 1 - (int)(r % KH); r /= KH;
-      c = (int)r;
-    } else {  // [(ky,kx,c)][n]
-      n = (int)(r % Np); r /= Np;
-      c = (int)(r % Cp); r /= Cp;
-      kx = (int)(r % KW); r /= KW;
-      ky = (int)r;
-    }
-    float v = 0.f;
-    if (n < N && c < C) v = w[(((long)n * C + c) * KH + ky) * KW + kx];
-    out[o] = from_f32<T>(v);
+    long o2;
+    const float v2 = pack_conv_elem(w, i, N, C, KH, KW, Np, Cp, mode, n_off, Nt, o2);
+    out[o2] = from_f32<T>(v2);
   }
 }
 
@@ -59,23 +117,8 @@ __global__ void pad_vector_kernel(const float* __restrict__ v, float* __restrict
 // kernel row: [Cp / 2 pairs][7 ky][16] = (w[ky][kx][2p], w[ky][kx][2p + 1]) for kx = 0..6, two pad floats
 __global__ void pack_dw_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int C, int Cp, int flip) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 49*Cp + (Cp/2)*7*16
-  if (i < 49 * Cp) {
-    const int tap = i / Cp, c = i - tap * Cp;
-    const int src_tap = flip ? 48 - tap : tap;
-    out[i] = c < C ? w[(long)c * 49 + src_tap] : 0.f;
-    return;
-  }
-  const int j = i - 49 * Cp;
-  if (j >= (Cp / 2) * 112) return;
-  const int p = j / 112, r = j - p * 112;
-  const int ky = r >> 4, e = r & 15;
-  const int kx = e >> 1, c = 2 * p + (e & 1);
-  float v = 0.f;
-  if (kx < 7 && c < C) {
-    const int tap = ky * 7 + kx;
-    v = w[(long)c * 49 + (flip ? 48 - tap : tap)];
-  }
-  out[i] = v;
+  float pv;
+  if (pack_dw_elem(w, i, C, Cp, flip, pv)) out[i] = pv;
 }
 
 __global__ void unpack_dw_wgrad_kernel(const float* __restrict__ gw, float* __restrict__ grad, int C, int Cp,
@@ -216,6 +259,13 @@ extern "C" int vkas_pad_vector(const float* v, float* out, int n, int np, void* 
   VKAS_CHECK(v && out && n > 0 && np >= n, "vkas_pad_vector: bad arguments");
   pad_vector_kernel<<<(unsigned)vkas_cdiv(np, 256), 256, 0, vkas_stream(stream)>>>(v, out, n, np);
   VKAS_LAUNCH_CHECK("pad_vector");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_pack_many(const vkas_pack_desc* descs, const int* block_start, int count, int total_blocks, void* stream) {
+  VKAS_CHECK(descs && block_start && count > 0 && total_blocks > 0, "vkas_pack_many: bad arguments");
+  pack_many_kernel<<<(unsigned)total_blocks, 256, 0, vkas_stream(stream)>>>(descs, block_start, count);
+  VKAS_LAUNCH_CHECK("pack_many");
   return VKAS_OK;
 }
 

@@ -104,11 +104,67 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 # epoch instead (training/optimizer.py).
 _PACK_CACHE = {}
 _PACK_EPOCH = [0]
+# Recipes of the cached images that one vkas_pack_many launch can rebuild (conv / depthwise weights of leaf parameters):
+# cache key -> (list of _lib.PackDesc, parameters as weak references, their data pointers when the recipe was recorded)
+_PACK_PLAN = {}
+_PACK_TABLE = [None]  # (plan keys, device table of descriptors, device block starts, entry count, workgroups)
 
 
 def invalidate_packed_params():
     _PACK_EPOCH[0] += 1
     _PACK_CACHE.clear()
+    _PACK_PLAN.clear()
+
+
+def _plan_pack(k, descs, params):
+    _PACK_PLAN[k] = (descs, tuple(weakref.ref(p) for p in params), tuple(p.data_ptr() for p in params))
+
+
+def _conv_desc(w4: torch.Tensor, out: torch.Tensor, Np: int, Cp: int, mode: int, n_off: int, Nt: int, dtype) -> _lib.PackDesc:
+    N, C, KH, KW = w4.shape
+    return _lib.PackDesc(w4.data_ptr(), out.data_ptr(), Np * KH * KW * Cp, 0, N, C, KH, KW, Np, Cp, mode, n_off, Nt, _dtc(dtype))
+
+
+def refresh_packed_params():
+    """All parameters were just updated in place (the fused optimizer: training/optimizer.py).  Instead of dropping the
+    packed operands and rebuilding them one launch at a time during the next step (~150 launches of a few microseconds),
+    rebuild every image with a recorded recipe by ONE vkas_pack_many launch - the parameters and the images keep their
+    addresses, so the descriptor table of a model is uploaded once - and drop only the rest."""
+    _PACK_EPOCH[0] += 1
+    live = {}
+    for k, (descs, refs, ptrs) in _PACK_PLAN.items():
+        params = [r() for r in refs]
+        if k in _PACK_CACHE and all(p is not None and p.data_ptr() == q for p, q in zip(params, ptrs)):
+            live[k] = (descs, refs, ptrs)
+    for k in list(_PACK_CACHE):
+        if k not in live:
+            del _PACK_CACHE[k]
+    _PACK_PLAN.clear()
+    _PACK_PLAN.update(live)
+    if not live:
+        return
+    keys = tuple(live)
+    tab = _PACK_TABLE[0]
+    if tab is None or tab[0] != keys:
+        descs = [d for k in keys for d in live[k][0]]
+        arr = (_lib.PackDesc * len(descs))(*descs)
+        starts = [0]
+        for d in descs:
+            starts.append(starts[-1] + (d.total + 2047) // 2048)
+        dev = _PACK_CACHE[keys[0]][2].device
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        tab = (keys, table, torch.tensor(starts, dtype=torch.int32, device=dev), len(descs), starts[-1])
+        _PACK_TABLE[0] = tab
+    check(lib.vkas_pack_many(_p(tab[1]), _p(tab[2]), tab[3], tab[4], _stream()), 'pack_many')
+    for k in keys:
+        stamp, refs, out = _PACK_CACHE[k]
+        if isinstance(refs, tuple):  # _cached_pack_multi
+            params = [r() for r in refs]
+            stamp = (tuple(p._version for p in params), _PACK_EPOCH[0], tuple(p.data_ptr() for p in params))
+        else:
+            src = refs()
+            stamp = (src._version, _PACK_EPOCH[0], src.data_ptr())
+        _PACK_CACHE[k] = (stamp, refs, out)
 
 
 def _cached_pack(src: torch.Tensor, key, build):
@@ -132,8 +188,11 @@ def pack_conv_weight(w: torch.Tensor, Np: int, Cp: int, mode: int, dtype: torch.
         out = torch.empty((Np * KH * KW * Cp,), dtype=dtype, device=w.device)
         check(lib.vkas_pack_conv_weight(_p(w4.contiguous()), _p(out), N, C, KH, KW, Np, Cp, mode,
                                         _dtc(dtype), _stream()), 'pack_conv_weight')
+        if w.is_leaf and w.requires_grad and w4.is_contiguous():
+            _plan_pack((id(w), key), [_conv_desc(w4, out, Np, Cp, mode, 0, Np, dtype)], [w])
         return out
-    return _cached_pack(w, ('conv', Np, Cp, mode, dtype), build)
+    key = ('conv', Np, Cp, mode, dtype)
+    return _cached_pack(w, key, build)
 
 
 def _cached_pack_pair(a: torch.Tensor, b: torch.Tensor, key, build):
@@ -182,8 +241,11 @@ def pack_dw_weight(w: torch.Tensor, C: int, Cp: int, flip: int) -> torch.Tensor:
     def build():
         out = torch.empty((lib.vkas_dw_weight_elems(Cp),), dtype=_FLOAT, device=w.device)
         check(lib.vkas_pack_dw_weight(_p(w.contiguous()), _p(out), C, Cp, flip, _stream()), 'pack_dw_weight')
+        if w.is_leaf and w.requires_grad and w.is_contiguous():
+            _plan_pack((id(w), key), [_lib.PackDesc(w.data_ptr(), out.data_ptr(), 105 * Cp, 1, 0, C, 0, 0, 0, Cp, flip, 0, 0, 0)], [w])
         return out
-    return _cached_pack(w, ('dw', C, Cp, flip), build)
+    key = ('dw', C, Cp, flip)
+    return _cached_pack(w, key, build)
 
 
 def pad_vector(v: Optional[torch.Tensor], npad: int) -> Optional[torch.Tensor]:
@@ -504,7 +566,7 @@ class Conv(Function):
         Hout = (Hin + 2 * pad - KH) // stride + 1
         Wout = (Win + 2 * pad - KW) // stride + 1
         Np = rup8(N)
-        Bw = pack_conv_weight(w4, Np, Cp, 0, x.dtype)
+        Bw = pack_conv_weight(weight, Np, Cp, 0, x.dtype)
         out = new_act(B, Hout, Wout, Np, x)
         geom = _geom(B, Hin, Win, Hout, Wout, Cp, act_ld(x), KH, KW, stride, pad)
         conv_gemm(x, geom, Bw, Np, out, _lib.EPI_NONE, bias=pad_vector(bias, Np), nk=(N, C * KH * KW))
@@ -527,13 +589,13 @@ class Conv(Function):
         if need_input_grad and ctx.needs_input_grad[0]:
             if stride == 1:
                 # dgrad = same-size conv of dy with the 180-degree rotated, in/out swapped kernel
-                Bt = pack_conv_weight(w4, Np, Cp, 1, x.dtype)
+                Bt = pack_conv_weight(weight, Np, Cp, 1, x.dtype)
                 dx = new_act(B, Hin, Win, Cp, x)
                 g2 = _geom(B, Hout, Wout, Hin, Win, Np, act_ld(dy), KH, KW, 1, KH - 1 - pad)
                 conv_gemm(dy, g2, Bt, Cp, dx, _lib.EPI_NONE, nk=(C, N * KH * KW))
             else:
                 assert stride == KH == KW and pad == 0
-                Bt = pack_conv_weight(w4, Np, Cp, 2, x.dtype)
+                Bt = pack_conv_weight(weight, Np, Cp, 2, x.dtype)
                 full = (Hout * stride == Hin and Wout * stride == Win)
                 dx = new_act(B, Hin, Win, Cp, x) if full else torch.zeros_like(x, memory_format=torch.contiguous_format)
                 g2 = _geom(B, Hout, Wout, Hout, Wout, Np, act_ld(dy), 1, 1, 1, 0)
@@ -644,14 +706,19 @@ def pack_head_weights(ws: Sequence[torch.Tensor], nps: Sequence[int], Cp: int, m
         KH, KW = ws[0].shape[2], ws[0].shape[3]
         out = torch.empty((Nt * KH * KW * Cp,), dtype=dtype, device=ws[0].device)
         off = 0
+        descs = []
         for w, np_ in zip(ws, nps):
             N, C = w.shape[0], w.shape[1]
             check(lib.vkas_pack_conv_weight_slice(_p(w.contiguous()), _p(out), N, C, KH, KW, np_, Cp, mode, off, Nt,
                                                   _dtc(dtype), _stream()),
                   'pack_conv_weight_slice')
+            descs.append(_conv_desc(w, out, np_, Cp, mode, off, Nt, dtype))
             off += np_
+        if all(w.is_leaf and w.requires_grad and w.is_contiguous() for w in ws):
+            _plan_pack((tuple(id(w) for w in ws), key), descs, list(ws))
         return out
-    return _cached_pack_multi(list(ws), ('heads', tuple(nps), Cp, mode, dtype), build)
+    key = ('heads', tuple(nps), Cp, mode, dtype)
+    return _cached_pack_multi(list(ws), key, build)
 
 
 class HeadsFused(Function):

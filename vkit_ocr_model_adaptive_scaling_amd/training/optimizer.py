@@ -78,7 +78,7 @@ class FlatAdamW:
                                       end - start, sumsq, float(self.max_grad_norm or 0.0), float(grad_scale),
                                       float(self.lr if lr is None else lr), self.betas[0], self.betas[1], self.eps,
                                       self.weight_decay, self.step_count, st), 'adamw_step')
-        ops.invalidate_packed_params()  # parameters changed behind autograd's version counters
+        ops.refresh_packed_params()  # parameters changed behind autograd's version counters: rebuild their packed images
 
     def grad_norm(self) -> float:
         """Host-visible total norm of the last step (forces a sync; for logging only)."""
