@@ -52,7 +52,7 @@ assert raw.vkas_trace_read(ctypes.c_void_p(buf.ctypes.data), ctypes.c_size_t(buf
 t = buf.reshape(-1, 8)
 nb = int((t[:, 0] != 0).sum())
 t = t[:nb].astype(np.int64)
-if os.environ.get('VKAS_NT_NOSTREAM') is None and M >= 16384:
+if t[:, 5].max() > 0 and t[:, 5].max() < 65536:  # a persistent kernel recorded its tile count (experiments/gemm_nt_stream_kernel.patch)
     print(f'  (streaming kernel: per workgroup, summed over its {int(np.median(t[:, 5]))} tiles: K loop = all K loops, epilogue = all epilogues)')
 print(f'M={M} N={N} K={K} mode={mode}: {nb} workgroups, launch {s.elapsed_time(e) * 1e3:.1f} us')
 xcc = t[:, 7] & 0xf
