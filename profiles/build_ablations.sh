@@ -13,5 +13,6 @@ for abl in "$@"; do
     fi
     objs="$objs $o"
   done
+  objs="$objs build/gemm_mfma_f16.o"
   hipcc --offload-arch=gfx950 -shared -fPIC $objs -o ../../build_variants/libvkas_abl$abl.so
 done

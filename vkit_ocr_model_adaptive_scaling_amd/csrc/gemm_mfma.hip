@@ -44,7 +44,8 @@ namespace {
 constexpr int BK = 64;
 
 // Timing-only ablation switches for profiles/ablate_nt.py (never defined in the shipped build; results are wrong when
-// set): 1 no global loads in the K loop, 2 no LDS staging writes, 4 no barrier, 8 fragments read once, 16 no MFMA.
+// set): 1 no global loads in the K loop, 2 no LDS staging writes, 4 no barrier, 8 fragments read once, 16 no MFMA,
+// 256 no fused head tail (the staging passes and their barriers stay).
 #ifndef VKAS_ABL
 #define VKAS_ABL 0
 #endif
@@ -71,8 +72,8 @@ __device__ __forceinline__ int swz_off(int row, int chunk) {  // element offset 
 // LPR = NTHR / ER lanes share a row (8 for the 8-wave tiles): each keeps up to VPL 8-channel vectors in registers,
 // row sums go through DPP shuffles inside the lane group.  The (M, C) activation is never written.
 template <int NTHR, int ER, int EP, int VPR>
-__device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head, const float* stage, long mrow0, long M,
-                                               int n0, int width, int tid) {
+__device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head, const float* stage, const float* hp,
+                                               long mrow0, long M, int n0, int width, int tid) {
   constexpr int LPR = NTHR / ER;
   constexpr int VPL = (VPR + LPR - 1) / LPR;
   static_assert(LPR == 4 || LPR == 8, "4 or 8 lanes per row");
@@ -80,7 +81,9 @@ __device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head,
   const long m = mrow0 + row;
   const int C = e.head.c[head];
   const int pw = e.head.pw;
-  const float* hp = e.head.params + (long)head * (6 * pw + 8);
+  // hp: this head's gamma | beta | Wproj[4] | bproj(8) | conv bias (pw), copied to LDS once per tile by the caller - every
+  // lane re-reads its 8-channel slices of them for every row (14 16-byte loads per vector: from global memory that was
+  // 1.5 MB through the L1 per tile and a quarter of the fused kernels' time)
   float v[VPL][8];
   float s = 0.f;
 #pragma unroll
@@ -92,7 +95,7 @@ __device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head,
       const float4 lo = *reinterpret_cast<const float4*>(stage + row * EP + c0);
       const float4 hi = *reinterpret_cast<const float4*>(stage + row * EP + c0 + 4);
       float b[8];
-      load8(e.bias + n0 + c0, b);
+      load8(hp + 6 * pw + 8 + c0, b);
       v[i][0] = lo.x + b[0]; v[i][1] = lo.y + b[1]; v[i][2] = lo.z + b[2]; v[i][3] = lo.w + b[3];
       v[i][4] = hi.x + b[4]; v[i][5] = hi.y + b[5]; v[i][6] = hi.z + b[6]; v[i][7] = hi.w + b[7];
     }
@@ -199,6 +202,14 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[TM][TN], float* stage, 
   } else {
     constexpr int EP = BN + 4;            // fp32 row pitch: pitch % 32 == 4 keeps the 16-byte writes conflict free
     constexpr int ER = TM * 16;           // rows per pass
+    // the head's parameter block and its slice of the conv bias behind the staged rows (visible after the first barrier)
+    float* hp_s = stage + ER * EP;
+    {
+      const int pw = e.head.pw, PSZ = 6 * pw + 8, width = n_end - n0;
+      const float* src = e.head.params + (long)tile_n * PSZ;
+      for (int i = tid; i < PSZ + pw; i += NTHR)
+        hp_s[i] = i < PSZ ? src[i] : ((i - PSZ < width && e.bias) ? e.bias[n0 + i - PSZ] : 0.f);
+    }
 #pragma unroll 1
     for (int pass = 0; pass < WM; ++pass) {
       if (wm == pass) {
@@ -210,7 +221,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[TM][TN], float* stage, 
                 acc[i][j];
       }
       __syncthreads();
-      head_tail_rows<NTHR, ER, EP, VPR>(e, tile_n, stage, m0 + (long)pass * ER, M, n0, n_end - n0, tid);
+      if constexpr ((ABL & 256) == 0)  // timing-only ablation: skip the head tail's arithmetic and stores
+        head_tail_rows<NTHR, ER, EP, VPR>(e, tile_n, stage, hp_s, m0 + (long)pass * ER, M, n0, n_end - n0, tid);
       __syncthreads();
     }
   }
@@ -437,7 +449,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const elem_t*
     if constexpr ((ABL & 4) == 0) __syncthreads();
   }
 
-  static_assert(TM * 16 * (BN + 4) * 4 <= 2 * (BM + BN) * BK * 2, "epilogue staging must fit the tile buffers");
+  static_assert(TM * 16 * (BN + 4) * 4 + (7 * 224 + 8) * 4 <= 2 * (BM + BN) * BK * 2, "epilogue staging must fit the tile buffers");
   VKAS_TR(2);
   nt_epilogue<WM, WN, TM, TN, HEAD>(acc, reinterpret_cast<float*>(lds), e, tile_n, m0, M, n0, n_end, tid);
   VKAS_TR(3);
@@ -486,7 +498,7 @@ __device__ __forceinline__ void conv3x3_slab_body(const elem_t* __restrict__ x, 
   constexpr int NBQ = (NWI + 7) / 8;         // ... per wave (waves >= RAG issue one less when NWI % 8 != 0)
   constexpr int RAG = NWI % 8;
   constexpr unsigned OOB = 0xFFFFFFF0u;
-  static_assert(TM * 16 * (BN + 4) * 4 <= (2 * SLAB + 3 * BT) * 2, "epilogue staging must fit");
+  static_assert(TM * 16 * (BN + 4) * 4 + (7 * 224 + 8) * 4 <= (2 * SLAB + 3 * BT) * 2, "epilogue staging must fit");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
