@@ -193,6 +193,11 @@ size_t vkas_layernorm_bwd_ws_bytes(long M, int Cp);
 /* gamma/beta (C), wproj (oc, C), bproj (oc) fp32 -> out[6*pw + 8] as laid out in vkas_head_desc */
 int vkas_pack_head_params(const float* gamma, const float* beta, const float* wproj, const float* bproj, int C, int oc,
                           int pw, float* out, void* stream);
+/* The same head tail as a pass of its own, for heads wider than the 224 columns the GEMM epilogue holds (ConvNeXt-Base /
+ * Large: model/upernext.py:215-223 with 256-258 / 384+ channels; pw <= 512): z (M, ld ldz) = the convolution's output incl.
+ * bias, written by a VKAS_EPI_NONE launch; hd->proj (n_heads, M, 8) and hd->stats (n_heads, M, 2; NULL = not kept) as
+ * VKAS_EPI_HEAD writes them. */
+int vkas_head_tail_fwd(const void* z, long ldz, const vkas_head_desc* hd, long M, int dtype, void* stream);
 /* backward of the fused tail for all heads of the launch at once: z / dz are the shared (M, sum np) buffers (strides ldz,
  * lddz), hd the descriptor used in the forward (params, stats; proj unused), dproj[h] the (M, 8) fp32 gradients of head
  * h's projection outputs -> dz and dparams[n_heads][6*pw + 8] (same layout as the packed parameters). */

@@ -641,7 +641,8 @@ def test_adamw_skips_parameters_without_gradient():
 
 
 @pytest.mark.parametrize('hw', [(128, 136), (66, 256)], ids=['generic', 'rowslab'])
-@pytest.mark.parametrize('chans', [((40, 33), (1, 4)), ((192, 193, 194, 194), (1, 2, 4, 4)), ((96,), (3,))])
+@pytest.mark.parametrize('chans', [((40, 33), (1, 4)), ((192, 193, 194, 194), (1, 2, 4, 4)), ((96,), (3,)),
+                                   ((256, 257, 258, 258), (1, 2, 4, 4)), ((384, 386), (1, 4))])  # Base / Large widths
 def test_heads_fused_matches_unfused_and_fp64(chans, hw):
     """Conv3x3 + per-head LayerNorm + GELU + Linear(C -> oc) fused into the GEMM epilogue (bf16) vs the same math in fp64
     on the host, forward and every gradient (input, conv weight / bias, gamma, beta, projection weight / bias)."""

@@ -97,6 +97,7 @@ _SIGS = {
                                    c_int, c_int, c_int, _P]),
     'vkas_layernorm_bwd_ws_bytes': (c_size_t, [c_long, c_int]),
     'vkas_pack_head_params': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
+    'vkas_head_tail_fwd': (c_int, [_P, c_long, _P, c_long, c_int, _P]),
     'vkas_head_tail_bwd': (c_int, [_P, c_long, POINTER(HeadDesc), POINTER(c_void_p), _P, c_long, _P, _P, c_size_t, c_long, c_int, _P]),
     'vkas_head_tail_bwd_ws_bytes': (c_size_t, [c_long, c_int]),
     'vkas_scale_res_bwd': (c_int, [_P, c_long, _P, c_long, _P, _P, c_int, _P, c_long, _P, _P, _P, c_size_t, c_long,

@@ -9,7 +9,8 @@ int vkas_colreduce_finalize(const float* partial, long P, int n, int ldp, float*
 
 namespace {
 
-constexpr int G = 32;   // lanes per pixel row (C <= 224 -> at most 28 8-channel vectors)
+// G = lanes per pixel row, one 8-channel vector each: 32 for heads up to 256 (padded) channels - ConvNeXt-T / S: 192-194 -,
+// 64 up to 512 (Base: 256-258, Large: 384+)
 constexpr int R = 2;    // rows in flight per lane group
 
 __global__ void pack_head_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -42,7 +43,7 @@ struct HeadBwdArgs {
 // OCM: upper bound of the heads' out_channels in this launch (1 for the rough pass: a quarter of the projection math and
 // 48 fewer accumulator registers).  The z / statistics / d(proj) loads of the NEXT row pair are issued before the current
 // pair is processed: with ~2 waves per SIMD the kernel was bound by the latency of one 16-byte load per lane per iteration.
-template <typename T, int NH, int OCM>
+template <typename T, int NH, int OCM, int G>
 __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict__ z, long ldz,
                                                             const float* __restrict__ params,
                                                             const float* __restrict__ stats, HeadBwdArgs a,
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
   const long mend = mbeg + rows_per_block < M ? mbeg + rows_per_block : M;
   const bool vok = hok && gl < nvec;
   // gamma | beta | Wproj[4] of every head live in LDS (each lane re-reads its 8-channel slice per row)
-  __shared__ __attribute__((aligned(16))) float sp[NH * 6 * 224];
+  __shared__ __attribute__((aligned(16))) float sp[NH * 6 * G * 8];
   for (int i = threadIdx.x; i < NH * 6 * pw; i += 256) {
     const int h = i / (6 * pw), r = i - h * 6 * pw;
     sp[i] = h < a.n_heads ? params[(long)h * PS + r] : 0.f;
@@ -236,7 +237,87 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
   }
 }
 
-static inline long ht_rows_per_block(long M) {
+// Forward side as a kernel of its own, for heads wider than the 224 columns the GEMM epilogue holds (ConvNeXt-Base / Large:
+// 256-258 / 384+ channels): the convolution writes z = acc + bias through its plain epilogue and this pass turns z into the
+// projected channels and the LayerNorm statistics - the (M, C) activation still never exists, z is read once.
+struct HeadFwdArgs {
+  int n_heads, pw;
+  int n0[4], np[4], c[4];
+};
+template <typename T, int NH, int G>
+__global__ __launch_bounds__(256) void head_tail_fwd_kernel(const T* __restrict__ z, long ldz, const float* __restrict__ params,
+                                                            float* __restrict__ stats, float* __restrict__ proj,
+                                                            HeadFwdArgs a, long M) {
+  constexpr int rpi = 256 / G / NH;
+  const int gl = threadIdx.x & (G - 1);
+  const int grp = threadIdx.x / G;
+  const int head = grp % NH, rl = grp / NH;
+  const bool hok = head < a.n_heads;
+  const int pw = a.pw, PS = 6 * pw + 8;
+  const int C = hok ? a.c[head] : 1, np = hok ? a.np[head] : 0, n0 = hok ? a.n0[head] : 0;
+  const bool vok = hok && gl < (np >> 3);
+  __shared__ __attribute__((aligned(16))) float sp[NH * (6 * G * 8 + 8)];
+  for (int i = threadIdx.x; i < NH * PS; i += 256) {
+    const int h = i / PS;
+    sp[i] = h < a.n_heads ? params[i] : 0.f;
+  }
+  __syncthreads();
+  const float* hp = sp + head * PS;
+  float gm[8], bt[8], wp[4][8], cm[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    gm[c] = bt[c] = 0.f;
+    cm[c] = (vok && gl * 8 + c < C) ? 1.f : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wp[q][c] = 0.f;
+  }
+  if (vok) {
+    load8(hp + gl * 8, gm);
+    load8(hp + pw + gl * 8, bt);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load8(hp + (2 + q) * pw + gl * 8, wp[q]);
+  }
+  const float invC = 1.f / (float)C;
+  for (long m = (long)blockIdx.x * rpi + rl; m < M; m += (long)gridDim.x * rpi) {
+    float x[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) x[c] = 0.f;
+    if (vok) load8(z + m * ldz + n0 + gl * 8, x);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s += x[c] * cm[c];
+    const float mean = group_sum<G>(s) * invC;
+    float q2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float d = (x[c] - mean) * cm[c];
+      q2 = fmaf(d, d, q2);
+    }
+    const float rstd = rsqrtf(group_sum<G>(q2) * invC + 1e-6f);
+    float pr[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float act = gelu_t<T>((x[c] - mean) * rstd * gm[c] + bt[c]) * cm[c];  // pad channels: gamma = beta = 0
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pr[q] = fmaf(act, wp[q][c], pr[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pr[q] = group_sum<G>(pr[q]);
+    if (gl == 0 && hok) {
+      const float4 bp = *reinterpret_cast<const float4*>(hp + 6 * pw);
+      float* po = proj + ((long)head * M + m) * 8;
+      *reinterpret_cast<float4*>(po) = make_float4(pr[0] + bp.x, pr[1] + bp.y, pr[2] + bp.z, pr[3] + bp.w);
+      *reinterpret_cast<float4*>(po + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (stats) {
+        stats[((long)head * M + m) * 2] = mean;
+        stats[((long)head * M + m) * 2 + 1] = rstd;
+      }
+    }
+  }
+}
+
+static inline int ht_lanes(int pw) { return pw <= 256 ? 32 : 64; }
+static inline long ht_rows_per_block(long M, int G) {
   long r = vkas_cdiv(M > 0 ? M : 1, 1024);
   if (r < 32) r = 32;
   const long q = (long)R * (256 / G);  // multiple of R * rpi for every NH
@@ -248,7 +329,7 @@ static inline long ht_rows_per_block(long M) {
 extern "C" int vkas_pack_head_params(const float* gamma, const float* beta, const float* wproj, const float* bproj, int C,
                                      int oc, int pw, float* out, void* stream) {
   VKAS_CHECK(gamma && beta && wproj && bproj && out, "vkas_pack_head_params: null pointer");
-  VKAS_CHECK(C > 0 && oc >= 1 && oc <= 4 && pw % 8 == 0 && pw >= C && pw <= 224, "vkas_pack_head_params: bad C=%d oc=%d pw=%d", C,
+  VKAS_CHECK(C > 0 && oc >= 1 && oc <= 4 && pw % 8 == 0 && pw >= C && pw <= 512, "vkas_pack_head_params: bad C=%d oc=%d pw=%d", C,
              oc, pw);
   pack_head_params_kernel<<<(unsigned)vkas_cdiv(6 * pw + 8, 256), 256, 0, vkas_stream(stream)>>>(gamma, beta, wproj, bproj, C,
                                                                                                 oc, pw, out);
@@ -257,14 +338,57 @@ extern "C" int vkas_pack_head_params(const float* gamma, const float* beta, cons
 }
 
 extern "C" size_t vkas_head_tail_bwd_ws_bytes(long M, int pw) {
-  return (size_t)vkas_cdiv(M > 0 ? M : 1, ht_rows_per_block(M)) * 4 * (size_t)(6 * pw + 8) * sizeof(float);
+  return (size_t)vkas_cdiv(M > 0 ? M : 1, ht_rows_per_block(M, ht_lanes(pw))) * 4 * (size_t)(6 * pw + 8) * sizeof(float);
+}
+
+extern "C" int vkas_head_tail_fwd(const void* z, long ldz, const vkas_head_desc* hd, long M, int dtype, void* stream) {
+  VKAS_CHECK(z && hd && hd->params && hd->proj, "vkas_head_tail_fwd: null pointer");
+  const int pw = hd->pw, nh = hd->n_heads;
+  VKAS_CHECK(nh >= 1 && nh <= 4 && pw % 8 == 0 && pw >= 8 && pw <= 512, "vkas_head_tail_fwd: bad descriptor");
+  HeadFwdArgs a;
+  a.n_heads = nh;
+  a.pw = pw;
+  for (int h = 0; h < 4; ++h) {
+    a.n0[h] = h < nh ? hd->n0[h] : 0;
+    a.np[h] = h < nh ? hd->np[h] : 0;
+    a.c[h] = h < nh ? hd->c[h] : 1;
+    if (h < nh) {
+      VKAS_CHECK(a.np[h] % 8 == 0 && a.np[h] > 0 && a.np[h] <= pw && a.c[h] > 0 && a.c[h] <= a.np[h] && a.n0[h] % 8 == 0 &&
+                     a.n0[h] + a.np[h] <= ldz && hd->oc[h] >= 1 && hd->oc[h] <= 4,
+                 "vkas_head_tail_fwd: bad head %d", h);
+    }
+  }
+  VKAS_CHECK(ldz % 8 == 0 && vkas_aligned16(z) && vkas_aligned16(hd->params) && vkas_aligned16(hd->proj),
+             "vkas_head_tail_fwd: bad strides/alignment");
+  if (M <= 0) return VKAS_OK;
+  hipStream_t st = vkas_stream(stream);
+  const int GL = ht_lanes(pw);
+  const int NH = nh == 1 ? 1 : (nh == 2 ? 2 : 4);
+  const long rows_per_iter = 256 / GL / NH;
+  long blocks = vkas_cdiv(M, rows_per_iter * 8);  // ~8 rows per lane group
+  if (blocks > 4096) blocks = 4096;
+#define VKAS_HF(NHV)                                                                                                          \
+  do {                                                                                                                        \
+    if (GL == 32)                                                                                                             \
+      head_tail_fwd_kernel<T, NHV, 32><<<(unsigned)blocks, 256, 0, st>>>((const T*)z, ldz, hd->params, hd->stats, hd->proj, a, M); \
+    else                                                                                                                      \
+      head_tail_fwd_kernel<T, NHV, 64><<<(unsigned)blocks, 256, 0, st>>>((const T*)z, ldz, hd->params, hd->stats, hd->proj, a, M); \
+  } while (0)
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_head_tail_fwd", {
+    if (NH == 1) VKAS_HF(1);
+    else if (NH == 2) VKAS_HF(2);
+    else VKAS_HF(4);
+  })
+#undef VKAS_HF
+  VKAS_LAUNCH_CHECK("head_tail_fwd");
+  return VKAS_OK;
 }
 
 extern "C" int vkas_head_tail_bwd(const void* z, long ldz, const vkas_head_desc* hd, const float* const* dproj, void* dz,
                                   long lddz, float* dparams, float* ws, size_t ws_bytes, long M, int dtype, void* stream) {
   VKAS_CHECK(z && hd && dproj && dz && dparams && ws && hd->params && hd->stats, "vkas_head_tail_bwd: null pointer");
   const int pw = hd->pw, nh = hd->n_heads;
-  VKAS_CHECK(nh >= 1 && nh <= 4 && pw % 8 == 0 && pw >= 8 && pw <= 224, "vkas_head_tail_bwd: bad descriptor");
+  VKAS_CHECK(nh >= 1 && nh <= 4 && pw % 8 == 0 && pw >= 8 && pw <= 512, "vkas_head_tail_bwd: bad descriptor");
   HeadBwdArgs a;
   a.n_heads = nh;
   a.pw = pw;
@@ -288,14 +412,20 @@ extern "C" int vkas_head_tail_bwd(const void* z, long ldz, const vkas_head_desc*
     (void)hipMemsetAsync(dparams, 0, (size_t)nh * PS * sizeof(float), st);
     return VKAS_OK;
   }
-  const long rpb = ht_rows_per_block(M);
+  const int GL = ht_lanes(pw);
+  const long rpb = ht_rows_per_block(M, GL);
   const long P = vkas_cdiv(M, rpb);
   const int NH = nh == 1 ? 1 : (nh == 2 ? 2 : 4);
   int ocm = 1;
   for (int h = 0; h < nh; ++h) ocm = hd->oc[h] > ocm ? hd->oc[h] : ocm;
   VKAS_CHECK(ocm <= 4, "vkas_head_tail_bwd: out_channels %d > 4", ocm);
-#define VKAS_HT(NHV, OCV) \
-  head_tail_bwd_kernel<T, NHV, OCV><<<(unsigned)P, 256, 0, st>>>((const T*)z, ldz, hd->params, hd->stats, a, (T*)dz, lddz, ws, M, rpb)
+#define VKAS_HT(NHV, OCV)                                                                                                      \
+  do {                                                                                                                         \
+    if (GL == 32)                                                                                                              \
+      head_tail_bwd_kernel<T, NHV, OCV, 32><<<(unsigned)P, 256, 0, st>>>((const T*)z, ldz, hd->params, hd->stats, a, (T*)dz, lddz, ws, M, rpb); \
+    else                                                                                                                       \
+      head_tail_bwd_kernel<T, NHV, OCV, 64><<<(unsigned)P, 256, 0, st>>>((const T*)z, ldz, hd->params, hd->stats, a, (T*)dz, lddz, ws, M, rpb); \
+  } while (0)
   VKAS_DISPATCH_DTYPE(dtype, "vkas_head_tail_bwd", {
     if (NH == 1) { if (ocm == 1) VKAS_HT(1, 1); else VKAS_HT(1, 4); }
     else if (NH == 2) { if (ocm == 1) VKAS_HT(2, 1); else VKAS_HT(2, 4); }

@@ -726,7 +726,8 @@ class HeadsFused(Function):
     GEMM whose epilogue applies each head's LayerNorm -> GELU -> Linear(C -> out_channels) per pixel: forward writes
     only the pre-LN conv output z (needed by backward) and the 1..4 projected channels; the (M, C) activations and
     their gradients never reach HBM.  Backward recomputes them tile-locally (vkas_head_tail_bwd) and feeds one dz into
-    the shared conv's dgrad / wgrad.  bf16 only; heads up to 224 channels and out_channels <= 4.
+    the shared conv's dgrad / wgrad.  bf16 / fp16; out_channels <= 4; heads up to 224 channels in the GEMM epilogue, up to
+    512 (ConvNeXt-Base / Large) through vkas_head_tail_fwd on z.
 
     inputs: x (B,H,W,Cp); then per head: conv weight (C_h, Cin, 3, 3), conv bias (C_h), gamma, beta, wproj (oc, C_h),
     bproj (oc).  The weights are packed side by side by the pack kernel (each head padded to a multiple of 8 rows).
@@ -735,7 +736,7 @@ class HeadsFused(Function):
     @staticmethod
     def eligible(x, channels, out_channels) -> bool:
         M = x.shape[0] * x.shape[1] * x.shape[2]
-        return (x.dtype in _MFMA_DTYPES and M >= 16384 and len(channels) <= 4 and max(rup8(c) for c in channels) <= 224
+        return (x.dtype in _MFMA_DTYPES and M >= 16384 and len(channels) <= 4 and max(rup8(c) for c in channels) <= 512
                 and max(out_channels) <= 4)
 
     @staticmethod
@@ -755,7 +756,10 @@ class HeadsFused(Function):
         assert all(tuple(w.shape) == (c, C, 3, 3) for w, c in zip(ws, cs)) and Cp == rup8(C)
         M = B * H * W
         wmax = max(nps)
-        pw = 128 if wmax <= 128 else (192 if wmax <= 192 else 224)
+        # up to 224 columns the tail runs in the convolution's epilogue (one 256 x pw tile per head); wider heads
+        # (ConvNeXt-Base / Large) take the plain epilogue + vkas_head_tail_fwd over z
+        in_epilogue = wmax <= 224
+        pw = (128 if wmax <= 128 else (192 if wmax <= 192 else 224)) if in_epilogue else wmax
         dev = x.device
 
         def build_hp():
@@ -776,7 +780,8 @@ class HeadsFused(Function):
         hp = _cached_pack_multi(list(gammas) + list(betas) + list(wps) + list(bps), ('head_params', pw), build_hp)
         b_cat = _cached_pack_multi(list(bs), ('head_bias', tuple(nps)), build_bias)
         # z and the row statistics only serve the backward pass: an inference (no-grad) call does not write them
-        z = new_act(B, H, W, Nt, x) if keep else None
+        # (the wide-head path needs z as the tail kernel's input either way)
+        z = new_act(B, H, W, Nt, x) if (keep or not in_epilogue) else None
         stats = torch.empty((n_heads, M, 2), dtype=_FLOAT, device=dev) if keep else None
         proj = torch.empty((n_heads, B, H, W, 8), dtype=_FLOAT, device=dev)
         head = _lib.HeadDesc()
@@ -788,7 +793,11 @@ class HeadsFused(Function):
         head.params, head.stats, head.proj = hp.data_ptr(), stats.data_ptr() if keep else None, proj.data_ptr()
         geom = _geom(B, H, W, H, W, Cp, act_ld(x), 3, 3, 1, 1)
         Bw = pack_head_weights(ws, nps, Cp, 0, x.dtype)
-        conv_gemm(x, geom, Bw, Nt, z, _lib.EPI_HEAD, bias=b_cat, nk=(sum(cs), C * 9), head=head)
+        if in_epilogue:
+            conv_gemm(x, geom, Bw, Nt, z, _lib.EPI_HEAD, bias=b_cat, nk=(sum(cs), C * 9), head=head)
+        else:
+            conv_gemm(x, geom, Bw, Nt, z, _lib.EPI_NONE, bias=b_cat, nk=(sum(cs), C * 9))
+            check(lib.vkas_head_tail_fwd(_p(z), Nt, ctypes.byref(head), M, _dt(x), _stream()), 'head_tail_fwd')
         if keep:
             ctx.save_for_backward(x, z, stats, hp, *ws, *bs)
         ctx.meta = (cs, ocs, nps, pw, C)
