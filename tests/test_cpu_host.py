@@ -247,3 +247,129 @@ def test_restore_state_roundtrip_and_torch_adamw_compat(tmp_path):
     assert rs.epoch_idx == 7 and set(rs.model_jit_state_dict) == set(ref.state_dict())
     for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
         assert torch.equal(p, q) and p.data_ptr() == fb.flat_param.data_ptr() + 4 * fb.offsets[n][0]
+
+
+def test_metrics_window_mean_matches_reference_update_rule():
+    """training/metrics.py:36-55 updates the window mean incrementally (avg + (new - popped) / n once the queue is full);
+    the mirror recomputes it from the window.  Same values, and reset() is per tag."""
+    from enum import Enum
+    from vkit_ocr_model_adaptive_scaling_amd.training import Metrics
+
+    class Tag(Enum):
+        A = 'a'
+        B = 'b'
+    m = Metrics(Tag, avg_num_batches=4)
+    rng = np.random.default_rng(0)
+    vals = rng.random(11).tolist()
+    queue, avg = [], None
+    for v in vals:
+        if not queue:
+            avg = v
+        elif len(queue) < 4:
+            avg = (avg * len(queue) + v) / (len(queue) + 1)
+        else:
+            avg = avg + (v - queue.pop(0)) / 4
+        queue.append(v)
+        got = m.update(Tag.A, v)
+        assert abs(got - avg) < 1e-12 and abs(got - sum(queue) / len(queue)) < 1e-15
+    assert m.tag_to_avg_value[Tag.B] is None and m.update(Tag.B, 2.0) == 2.0
+    m.reset([Tag.A])
+    assert m.tag_to_avg_value[Tag.A] is None and m.tag_to_avg_value[Tag.B] == 2.0
+    assert m.update(Tag.A, 5.0) == 5.0
+
+
+def test_collate_schema_and_synthetic_dataset():
+    """dataset/adaptive_scaling.py:282-368: keys, dtypes and shapes of the collated batch; the synthetic source is
+    index-deterministic (the same sample whatever the worker layout) and feeds a torch DataLoader."""
+    from torch.utils.data import DataLoader
+    from vkit_ocr_model_adaptive_scaling_amd.dataset import (SyntheticAdaptiveScalingIterableDataset,
+                                                             adaptive_scaling_dataset_collate_fn)
+    ds = SyntheticAdaptiveScalingIterableDataset(6, (96, 128), num_label_points=7, margin=10, rng_seed=3)
+    batches = list(DataLoader(ds, batch_size=3, collate_fn=adaptive_scaling_dataset_collate_fn))
+    assert len(batches) == 2
+    b = batches[0]
+    assert set(b) == {'rough', 'precise'}
+    common = {'image': ((3, 3, 96, 128), torch.float32), 'downsampled_mask': ((3, 28, 44), torch.float32),
+              'downsampled_score_map': ((3, 28, 44), torch.float32)}
+    extra = {'downsampled_label_point_y': ((3, 7), torch.int64), 'downsampled_label_point_x': ((3, 7), torch.int64),
+             'up_left_offsets': ((3, 7, 2), torch.int64), 'corner_angles': ((3, 7, 4), torch.float32),
+             'corner_distances': ((3, 7, 3), torch.float32)}
+    for part, spec in (('rough', common), ('precise', {**common, **extra})):
+        assert set(b[part]) == set(spec) | {'downsampled_shape', 'downsampled_core_box', 'rng_states'}
+        for k, (shape, dt) in spec.items():
+            assert tuple(b[part][k].shape) == shape and b[part][k].dtype == dt, (part, k)
+        assert b[part]['downsampled_shape'] == (48, 64) and len(b[part]['rng_states']) == 3
+        box = b[part]['downsampled_core_box']
+        assert (box.up, box.down, box.left, box.right) == (10, 37, 10, 53)
+    p = b['precise']
+    assert float(p['image'].max()) <= 255.0 and float(p['image'].min()) >= 0.0
+    assert int(p['downsampled_label_point_y'].min()) >= 10 and int(p['downsampled_label_point_y'].max()) <= 37
+    assert torch.allclose(p['corner_angles'].sum(-1), torch.ones(3, 7), atol=1e-6)
+    r0, p0 = ds.sample(4)
+    r1, p1 = SyntheticAdaptiveScalingIterableDataset(6, (96, 128), num_label_points=7, rng_seed=3).sample(4)
+    assert np.array_equal(r0.image, r1.image) and np.array_equal(p0.up_left_offsets, p1.up_left_offsets)
+    two = list(DataLoader(ds, batch_size=3, num_workers=0, collate_fn=adaptive_scaling_dataset_collate_fn))
+    assert torch.equal(two[1]['rough']['image'], batches[1]['rough']['image'])
+
+
+def test_run_training_loop_rules(tmp_path):
+    """The epoch loop's host logic (train.py:340-605) with a stand-in step: learning rate per step = the scheduler value
+    set AFTER the previous step, dev means, and the checkpoint rule / file names."""
+    import types
+    from vkit_ocr_model_adaptive_scaling_amd.training import (EpochConfig, OptimizerConfig, FlatBuffers, run_training,
+                                                              cosine_warm_restarts_lr, load_restore_state)
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(2, 1)
+
+        def forward_rough(self, x):
+            return x.mean(), x.mean()
+
+        def forward_precise(self, x):
+            return x.mean(), x.mean(), x.mean(), x.mean()
+    model = Toy()
+    fb = FlatBuffers(model.named_parameters())
+    opt = types.SimpleNamespace(flat=fb, exp_avg=torch.zeros(fb.numel), exp_avg_sq=torch.zeros(fb.numel), step_count=0,
+                                lr=8e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    lrs, dev_values = [], iter([3.0, 1.0, 2.0, 2.5])  # dev loss per epoch (rough == precise == value / 2 each)
+
+    class Step:
+        def __init__(self):
+            self.model, self.optimizer = model, opt
+            self.cur = None
+
+        def __call__(self, rough, precise, lr=None):
+            lrs.append(lr)
+            opt.step_count += 1
+            return torch.tensor(0.25), torch.tensor(0.75)
+
+        def _rough_loss(self, outs, b, scale):
+            return torch.tensor(self.cur * scale)
+
+        def _precise_loss(self, outs, b, scale):
+            return torch.tensor(self.cur * scale)
+    step = Step()
+    batch = {'rough': {'image': torch.zeros(1, 3, 4, 4)}, 'precise': {'image': torch.zeros(1, 3, 4, 4)}}
+
+    def dev():
+        step.cur = next(dev_values)
+        return [batch, batch]
+    ec = EpochConfig(num_epochs=4, train_num_batches=3, dev_num_batches=2, avg_num_batches=2)
+    oc = OptimizerConfig()
+    res = run_training(step, lambda e: [batch] * 5, dev, ec, oc, str(tmp_path), torch.device('cpu'),
+                       dataset_switch_epochs=(3,))
+    # 3 batches per epoch even though the loader offers 5; first step at the base rate, then the rate of the previous call
+    rule = lambda t: cosine_warm_restarts_lr(t, 8e-4, 8e-6, 10, 10)
+    want = [rule(0.0)] + [rule(e + (b - 1) / 3) for e in range(4) for b in range(1, 4)][:-1]
+    assert len(lrs) == 12 and all(abs(a - b) < 1e-15 for a, b in zip(lrs, want))
+    assert [round(r.dev_loss, 6) for r in res] == [3.0, 1.0, 2.0, 2.5]
+    assert [r.dev_rough_loss for r in res] == [1.5, 0.5, 1.0, 1.25]
+    names = [None if r.state_dict_path is None else os.path.basename(r.state_dict_path) for r in res]
+    # epoch 0 best, epoch 1 best, epoch 2 saved because a dataset switch follows (epoch 3), epoch 3 is the last
+    assert names == ['state_dict_0.pt', 'state_dict_1.pt', 'state_dict_2_not_best.pt', 'state_dict_3_not_best.pt']
+    rs = load_restore_state(res[1].state_dict_path)
+    assert rs.epoch_idx == 1 and set(rs.model_jit_state_dict) == {'lin.weight', 'lin.bias'}
+    sd = rs.optimizer_scheduler_state_dict  # the scheduler's state after its last call of epoch 1: step(1 + 2/3)
+    assert sd['last_epoch'] == 1 and abs(sd['T_cur'] - (1 + 2 / 3)) < 1e-12

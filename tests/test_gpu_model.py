@@ -464,3 +464,51 @@ def test_batched_repack_matches_lazy_packs():
     ops.refresh_packed_params()
     ops.refresh_packed_params()
     assert ops._PACK_TABLE[0][1].data_ptr() == table
+
+
+def test_harness_two_epochs_end_to_end(tmp_path):
+    """train.py's loop (training/harness.py) on the device: synthetic loader -> collate -> TwoPassStep (merged schedule,
+    FlatAdamW) -> dev evaluation -> RestoreState checkpoint; the loss goes down on a repeated batch and the checkpoint
+    restores the evaluated model."""
+    from torch.utils.data import DataLoader
+    from vkit_ocr_model_adaptive_scaling_amd.dataset import (SyntheticAdaptiveScalingIterableDataset,
+                                                             adaptive_scaling_dataset_collate_fn)
+    from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
+                                                           AdaptiveScalingNeckHeadType)
+    from vkit_ocr_model_adaptive_scaling_amd.loss_function import (
+        AdaptiveScalingRoughLossFunction, AdaptiveScalingRoughLossFunctionConifg,
+        AdaptiveScalingPreciseLossFunction, AdaptiveScalingPreciseLossFunctionConifg)
+    from vkit_ocr_model_adaptive_scaling_amd.training import (FlatBuffers, FlatAdamW, TwoPassStep, EpochConfig,
+                                                              OptimizerConfig, run_training, load_restore_state, evaluate,
+                                                              Metrics, MetricsTag, setup_seeds)
+    setup_seeds(torch_seed=7)
+    dev = torch.device('cuda')
+    model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.TINY, AdaptiveScalingNeckHeadType.UPERNEXT)).to(dev)
+    flat = FlatBuffers(model.named_parameters())
+    oc = OptimizerConfig(adamw_lr=2e-4)
+    opt = FlatAdamW(None, lr=oc.adamw_lr, betas=oc.adamw_betas, weight_decay=oc.adamw_weight_decay,
+                    max_grad_norm=oc.clip_grad_norm_max_norm, flat=flat)
+    step = TwoPassStep(model, AdaptiveScalingRoughLossFunction(AdaptiveScalingRoughLossFunctionConifg()),
+                       AdaptiveScalingPreciseLossFunction(AdaptiveScalingPreciseLossFunctionConifg()), opt,
+                       merge_backbone=True)
+    ec = EpochConfig(num_epochs=2, train_num_batches=3, train_batch_size=2, dev_num_batches=1, dev_batch_size=2,
+                     avg_num_batches=2, num_page_char_regression_labels=16)
+
+    def loader(seed, n):
+        ds = SyntheticAdaptiveScalingIterableDataset(n, (256, 256), num_label_points=ec.num_page_char_regression_labels,
+                                                     rng_seed=seed)
+        return DataLoader(ds, batch_size=2, collate_fn=adaptive_scaling_dataset_collate_fn, pin_memory=True)
+    # the same two samples every batch of every epoch: the loss has to fall
+    results = run_training(step, lambda e: list(loader(11, 2)) * ec.train_num_batches, lambda: loader(11, 2), ec, oc,
+                           str(tmp_path), dev)
+    assert len(results) == 2 and all(np.isfinite(r.dev_loss) for r in results)
+    assert results[1].dev_loss < results[0].dev_loss
+    assert results[0].state_dict_path.endswith('state_dict_0.pt') and results[1].state_dict_path.endswith('state_dict_1.pt')
+    assert opt.step_count == 6
+    # the checkpoint holds the evaluated model: a fresh module restored from it reproduces the dev loss
+    model2 = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.TINY, AdaptiveScalingNeckHeadType.UPERNEXT)).to(dev)
+    rs = load_restore_state(results[1].state_dict_path, model2)
+    assert rs.epoch_idx == 1 and int(float(rs.optimizer_state_dict['state'][0]['step'])) == 6
+    step2 = TwoPassStep(model2, step.rough_loss_fn, step.precise_loss_fn, opt)
+    r2, p2, l2 = evaluate(step2, loader(11, 2), dev, Metrics(MetricsTag, 2), 1, 1)
+    assert abs(l2 - results[1].dev_loss) < 2e-3 * abs(results[1].dev_loss)
