@@ -62,10 +62,7 @@ class FpnNeck(nn.Module):
         for i in range(n - 1, 0, -1):
             outs[i - 1] = ops.ResizeAdd.apply(outs[i - 1], outs[i], NEAREST)
         outs = [helper.conv_block(o, blk[0], blk[2], 1, 1) for o, blk in zip(outs, self.step2_conv_blocks)]
-        size0 = (feats[0].shape[1], feats[0].shape[2])
-        for i in range(1, n):
-            outs[i] = ops.Resize.apply(outs[i], size0, NEAREST)
-        return ops.Cat.apply(*outs)
+        return ops.ResizeCat.apply(NEAREST, *outs)  # every level resized to the finest one and concatenated (fpn.py:131-144)
 
     def forward(self, features: List[torch.Tensor]) -> torch.Tensor:  # type: ignore
         acts = [helper.nchw_to_act(f, self.compute_dtype) for f in features]

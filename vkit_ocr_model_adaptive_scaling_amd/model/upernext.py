@@ -46,13 +46,11 @@ class PpmBlock(nn.Module):
         self.compute_dtype = torch.bfloat16
 
     def forward_act(self, x: torch.Tensor) -> torch.Tensor:
-        size = (x.shape[1], x.shape[2])
-        parts = [x]
+        parts = []
         for s, branch in zip(self.ppm_scales, self.ap_conv_blocks):
             f = ops.AdaptiveAvgPool.apply(x, s)
-            f = helper.conv_block(f, branch[1][1], branch[1][2])
-            parts.append(ops.Resize.apply(f, size, BILINEAR))
-        cat = ops.Cat.apply(*parts)
+            parts.append(helper.conv_block(f, branch[1][1], branch[1][2]))
+        cat = ops.ResizeCat.apply(BILINEAR, x, *parts)  # the pooled branches resized to x and concatenated behind it
         return helper.conv_block(cat, self.final_conv_block[0], self.final_conv_block[2], 1, 1)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # type: ignore
@@ -100,10 +98,9 @@ class UperNextNeck(nn.Module):
             outs[i - 1] = ops.ResizeAdd.apply(outs[i - 1], outs[i], BILINEAR)
         for i, blk in enumerate(self.step2_conv_blocks):
             outs[i] = helper.conv_block(outs[i], blk[0], blk[2], 1, 1)
-        size0 = (feats[0].shape[1], feats[0].shape[2])
-        for i in range(1, n):
-            outs[i] = ops.Resize.apply(outs[i], size0, BILINEAR)
-        return ops.Cat.apply(*outs)
+        # every level resized to the finest one and concatenated (upernext.py:184-197): one op, the resize kernels write
+        # into their channel slices
+        return ops.ResizeCat.apply(BILINEAR, *outs)
 
     def forward(self, features: List[torch.Tensor]) -> torch.Tensor:  # type: ignore
         acts = [helper.nchw_to_act(f, self.compute_dtype) for f in features]

@@ -1192,6 +1192,39 @@ class Cat(Function):
         return tuple(outs)
 
 
+class ResizeCat(Function):
+    """torch.cat([first] + [F.interpolate(p, first's size) for p in others], channels) (model/upernext.py:184-197): the
+    resize kernels write straight into their channel slice of the concatenated buffer, so only ``first`` is copied; backward
+    reads each slice of the incoming gradient in place."""
+
+    @staticmethod
+    def forward(ctx, mode: int, first, *others):
+        _require_cuda(first, *others)
+        first = as_act(first)
+        others = [as_act(p) for p in others]
+        B, H, W, w0 = first.shape
+        widths = [w0] + [p.shape[3] for p in others]
+        out = new_act(B, H, W, sum(widths), first)
+        copy_channels(first, out[..., :w0])
+        off = w0
+        for p in others:
+            resize_fwd(p, (H, W), mode, out=out[..., off:off + p.shape[3]])
+            off += p.shape[3]
+        ctx.cfg = (mode, widths, [(p.shape[1], p.shape[2]) for p in others])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        mode, widths, in_sizes = ctx.cfg
+        dy = as_act(dy)
+        grads = [dy[..., :widths[0]]]
+        off = widths[0]
+        for w, size in zip(widths[1:], in_sizes):
+            grads.append(resize_bwd(dy[..., off:off + w], size, mode))
+            off += w
+        return (None, *grads)
+
+
 class SplitBatch(Function):
     """x -> (x[:b0], x[b0:]) as views of one NHWC activation; backward writes the two gradients into the halves of one
     buffer (no zero-fill + add, which is what slicing through autograd would do).  Used by the merged pass schedule
