@@ -45,6 +45,20 @@ def main():
         ms = timeit(fwd)
         if quick:
             print(f'{os.environ.get("VKAS_LIB_PATH", "libvkas.so"):40s} fwd {ms * 1e3:7.1f} us', flush=True)
+            if '--trace' in sys.argv:  # -DDW_TRACE build: where a workgroup's tile iterations spend their cycles
+                import numpy as np
+                raw = ctypes.CDLL(os.environ['VKAS_LIB_PATH'])
+                buf = np.zeros(8192 * 8, dtype=np.uint64)
+                assert raw.vkas_dw_trace_read(ctypes.c_void_p(buf.ctypes.data), ctypes.c_size_t(buf.nbytes)) == 0
+                t = buf.reshape(-1, 8).astype(np.float64)
+                t = t[t[:, 6] > 0]
+                per = t[:, :6] / t[:, 6:7]
+                names = ('fetch issue', 'matrix products (+ lgkmcnt)', 'barrier 1', 'result planes -> y', 'staging (+ lgkmcnt)',
+                         'barrier 2')
+                print(f'  {len(t)} workgroups, {np.median(t[:, 6]):.0f} tiles each; median cycles per tile:')
+                for i, n in enumerate(names):
+                    print(f'    {n:30s} {np.median(per[:, i]):8.0f}')
+                print(f'    {"sum":30s} {np.median(per.sum(1)):8.0f}')
             continue
         ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, bias, padding=3, groups=C).permute(0, 2, 3, 1)
         err = float((y.float() - ref).norm() / ref.norm())

@@ -10,7 +10,9 @@ for abl in "$@"; do
     o=build/${f%.hip}.o
     if [ "$f" = dwconv.hip ]; then
       o=../../build_variants/dwconv_abl$abl.o
-      hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-value -DDW_ABL=$abl -c $f -o $o
+      flags="-DDW_ABL=$abl"
+      [ "$abl" = trace ] && flags="-DDW_TRACE"
+      hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-value $flags -c $f -o $o
     fi
     objs="$objs $o"
   done

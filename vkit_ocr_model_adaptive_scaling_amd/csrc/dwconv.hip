@@ -146,6 +146,20 @@ static_assert(PPW >= PIY * PPITCH && PPW >= 2 * PTY * PTX && PPW % 32 == 2, "pla
 
 // Timing-only ablation switches (never set in the shipped build): 1 no FMAs, 2 no LDS row reads, 4 no weight loads,
 // 8 no halo loads, 16 no output phase.
+// -DDW_TRACE (profiling builds only): per-workgroup sums of s_memtime cycles spent in the phases of dwconv7x7_mfma_kernel's
+// tile loop - 0 fetch issue, 1 matrix products, 2 barrier, 3 result planes -> y, 4 staging, 5 barrier, 6 tiles -, read with
+// vkas_dw_trace_read (profiles/trace_dw.py)
+#ifdef DW_TRACE
+__device__ unsigned long long vkas_dw_trace_buf[8192 * 8];
+#define DW_TR(i)                                             \
+  do {                                                       \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    tr_acc[i] += now_ - tr_last;                             \
+    tr_last = now_;                                          \
+  } while (0)
+#else
+#define DW_TR(i)
+#endif
 #ifndef DW_ABL
 #define DW_ABL 0
 #endif
@@ -439,21 +453,31 @@ __global__ __launch_bounds__(512, 4) void dwconv7x7_mfma_kernel(const T* __restr
     y0 = ty * MTY;
     x0 = tx * MTX;
   };
-  // halo tile: item = (pixel, 8-channel chunk of the slice); loads of a thread are issued together
+  // halo tile: item = (pixel, 8-channel chunk of the slice); loads of a thread are issued together.  An item's position
+  // inside the tile is the same for every tile of the walk: (iy, ix) is decoded once (the divisions by the 38-pixel row
+  // were 1.3k of a tile's 8.4k cycles, phase timestamps of the -DDW_TRACE build)
   uint4 sv[NSTG];
+  int item_yx[NSTG];  // iy << 8 | ix, -1 = no item
+#pragma unroll
+  for (int k = 0; k < NSTG; ++k) {
+    const int it = tid + k * NTHR;
+    const int q = it >> 1;
+    const int iy = q / MIX, ix = q - iy * MIX;
+    item_yx[k] = it < NITEM ? (iy << 8 | ix) : -1;
+  }
+  const int chunk = tid & 1;  // NTHR is even: the same for all items of a thread
+  const bool c_ok = c0 + chunk * 8 < Cp;
   auto fetch = [&](int t) {
     int b, y0, x0;
     decode(t, b, y0, x0);
+    const T* xb = x + (((long)b * H + (y0 - 3)) * W + (x0 - 3)) * ldx + c0 + chunk * 8;
 #pragma unroll
     for (int k = 0; k < NSTG; ++k) {
-      const int it = tid + k * NTHR;
-      const int chunk = it & 1, q = it >> 1;
-      const int iy = q / MIX, ix = q - iy * MIX;
+      const int iy = item_yx[k] >> 8, ix = item_yx[k] & 255;
       const int gy = y0 + iy - 3, gx = x0 + ix - 3;
-      const int c = c0 + chunk * 8;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (it < NITEM && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cp && !(DW_ABL & 8))
-        v = *reinterpret_cast<const uint4*>(x + (((long)b * H + gy) * W + gx) * ldx + c);
+      if (item_yx[k] >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c_ok && !(DW_ABL & 8))
+        v = *reinterpret_cast<const uint4*>(xb + ((long)iy * W + ix) * ldx);
       sv[k] = v;
     }
   };
@@ -461,10 +485,8 @@ __global__ __launch_bounds__(512, 4) void dwconv7x7_mfma_kernel(const T* __restr
   auto stage = [&]() {
 #pragma unroll
     for (int k = 0; k < NSTG; ++k) {
-      const int it = tid + k * NTHR;
-      if (it < NITEM && !(DW_ABL & 2)) {
-        const int chunk = it & 1, q = it >> 1;
-        const int iy = q / MIX, ix = q - iy * MIX;
+      if (item_yx[k] >= 0 && !(DW_ABL & 2)) {
+        const int iy = item_yx[k] >> 8, ix = item_yx[k] & 255;
         unsigned short* dst = reinterpret_cast<unsigned short*>(in_planes) + chunk * MPB_IN + iy * MIP + ix + 5;
         const unsigned wd[4] = {sv[k].x, sv[k].y, sv[k].z, sv[k].w};
 #pragma unroll
@@ -482,11 +504,15 @@ __global__ __launch_bounds__(512, 4) void dwconv7x7_mfma_kernel(const T* __restr
   __syncthreads();  // zero fill done, the weight table in the result planes has been read
   stage();
   __syncthreads();
+#ifdef DW_TRACE
+  unsigned long long tr_acc[7] = {0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_readcyclecounter();
+#endif
   for (; t < nsp; t += wg_per_slice) {
     int b, y0, x0;
     decode(t, b, y0, x0);
     const bool more = t + wg_per_slice < nsp;
     if (more) fetch(t + wg_per_slice);  // in flight behind this tile's matrix products
+    DW_TR(0);
 
     // ---- compute: 7 MFMAs per (channel, 16-column group); D[i][j]: lane holds out x = 4g .. 4g+3 of row j = li
 #pragma unroll
@@ -499,18 +525,24 @@ __global__ __launch_bounds__(512, 4) void dwconv7x7_mfma_kernel(const T* __restr
         f32x4 acc = {bv[cc], bv[cc], bv[cc], bv[cc]};
 #pragma unroll
         for (int ky = 0; ky < 7; ++ky) {
-          const v8 bf = *reinterpret_cast<const v8*>(pl + ky * MIP + xg * 16);
-          acc = dw_mfma(af[cc][ky], bf, acc);
+          v8 bf;
+          if (DW_ABL & 64) bf = af[cc][(ky + 1) % 7];  // timing only: no fragment reads
+          else bf = *reinterpret_cast<const v8*>(pl + ky * MIP + xg * 16);
+          if (DW_ABL & 32) acc[ky & 3] += (float)bf[ky];  // timing only: no MFMA
+          else acc = dw_mfma(af[cc][ky], bf, acc);
         }
-        *reinterpret_cast<f32x4*>(out_planes + P * MPB_OUT + li * MOP + xg * 16 + 4 * g) = acc;
+        if (!(DW_ABL & 128)) *reinterpret_cast<f32x4*>(out_planes + P * MPB_OUT + li * MOP + xg * 16 + 4 * g) = acc;
+        else asm volatile("" ::"v"(acc));
         asm volatile("" ::: "memory");  // keep the 7 fragment reads of the next group here (hoisting all 56 spills)
       }
     }
     // LDS-only barrier: __syncthreads() would also drain the vector-memory queue, i.e. wait for the prefetch just issued
     // and for the previous tile's stores at every tile (6 us per tile instead of ~2)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    DW_TR(1);
     __builtin_amdgcn_s_barrier();  // results complete; the input planes are free
     asm volatile("" ::: "memory");
+    DW_TR(2);
 
     // ---- fp32 result planes -> 16-byte channel chunks of y (+ the residual): item = (pixel, chunk)
     constexpr int NOUT = (DW_ABL & 4) ? 0 : MTY * MTX * 2 / NTHR;
@@ -535,12 +567,22 @@ __global__ __launch_bounds__(512, 4) void dwconv7x7_mfma_kernel(const T* __restr
         store8(y + pix * ldy + c, o);
       }
     }
+    DW_TR(3);
+#ifdef DW_TRACE
+    tr_acc[6] += 1;
+#endif
     if (!more) break;
     stage();          // next halo tile (registers) -> input planes
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    DW_TR(4);
     __builtin_amdgcn_s_barrier();  // ... visible, and the result planes have been read
     asm volatile("" ::: "memory");
+    DW_TR(5);
   }
+#ifdef DW_TRACE
+  if (tid == 0 && blockIdx.x < 8192)
+    for (int i = 0; i < 7; ++i) vkas_dw_trace_buf[blockIdx.x * 8 + i] = tr_acc[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -898,6 +940,12 @@ extern "C" int vkas_dwconv7x7_fwd(const void* x, long ldx, const float* w, const
 static long dw_wgrad_parts(int B, int H, int W) {
   return (long)B * vkas_cdiv(vkas_cdiv(H, TY), YG) * vkas_cdiv(W, TX);
 }
+
+#ifdef DW_TRACE
+extern "C" int vkas_dw_trace_read(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(vkas_dw_trace_buf), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" size_t vkas_dwconv7x7_wgrad_ws_bytes(int B, int H, int W, int Cp) {
   long parts = dw_wgrad_parts(B, H, W);
