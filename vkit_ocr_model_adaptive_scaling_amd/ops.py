@@ -499,7 +499,8 @@ def resize_fwd(x, size: Tuple[int, int], mode: int, out=None, accumulate=False):
     Hout, Wout = size
     y = new_act(B, Hout, Wout, Cp, x) if out is None else out
     nbytes = B * Cp * x.element_size() * (Hin * Win + Hout * Wout * (2 if accumulate else 1))
-    _timed('resize_fwd_kernel', x, 0.0, B * Hout * Wout, Cp, 0,
+    x2 = mode == 0 and Hout == 2 * Hin and Wout == 2 * Win and Hin > 1 and Win > 1  # the library's exact-x2 kernels
+    _timed('resize2x_fwd_kernel' if x2 else 'resize_fwd_kernel', x, 0.0, B * Hout * Wout, Cp, 0,
            lambda: check(lib.vkas_resize_fwd(_p(x), act_ld(x), _p(y), act_ld(y), B, Hin, Win, Hout, Wout, Cp, mode,
                                              int(accumulate), _dt(x), _stream()), 'resize_fwd'), nbytes)
     return y
@@ -510,7 +511,8 @@ def resize_bwd(dy, in_size: Tuple[int, int], mode: int):
     Hin, Win = in_size
     dx = new_act(B, Hin, Win, Cp, dy)
     nbytes = B * Cp * dy.element_size() * (Hin * Win + Hout * Wout)
-    _timed('resize_bwd_kernel', dy, 0.0, B * Hout * Wout, Cp, 0,
+    x2 = mode == 0 and Hout == 2 * Hin and Wout == 2 * Win and Hin > 1 and Win > 1
+    _timed('resize2x_bwd_kernel' if x2 else 'resize_bwd_kernel', dy, 0.0, B * Hout * Wout, Cp, 0,
            lambda: check(lib.vkas_resize_bwd(_p(dy), act_ld(dy), _p(dx), act_ld(dx), B, Hin, Win, Hout, Wout, Cp, mode, 0,
                                              _dt(dy), _stream()), 'resize_bwd'), nbytes)
     return dx
