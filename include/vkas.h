@@ -320,10 +320,12 @@ typedef struct {
   long total;
   int kind, N, C, KH, KW, Np, Cp, mode, n_off, Nt, dtype;
 } vkas_pack_desc;
-/* descs (count entries) and block_start (count + 1 ints: first workgroup of every entry, 2048 elements per workgroup;
- * block_start[count] = total_blocks) live in DEVICE memory and stay valid until the launch has run: the table of a model is
+/* descs (count entries) and block_start (count + 1 ints: first workgroup of every entry - an entry takes
+ * vkas_pack_many_blocks(&desc) workgroups -; block_start[count] = total_blocks) live in DEVICE memory and stay valid until the launch has run: the table of a model is
  * built once and re-used every step (the parameters and their images keep their addresses). */
 int vkas_pack_many(const vkas_pack_desc* descs, const int* block_start, int count, int total_blocks, void* stream);
+/* workgroups entry d takes: 32 x 64 tiles of the transposed image for kind 0 / mode 1 (dgrad layout), else 2048 elements each */
+int vkas_pack_many_blocks(const vkas_pack_desc* d);
 
 /* ---- inference post-processing on the device: inferencing/adaptive_scaling.py:129-188,318-396 ------------------------ */
 /* mask_logit, height (B,1,H,W) fp32 -> out_mask (B,H,W) uint8 = sigmoid >= mask_thr, out_height (B,H,W) fp32 = height where

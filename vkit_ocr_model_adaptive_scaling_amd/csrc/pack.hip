@@ -67,7 +67,43 @@ __global__ __launch_bounds__(256) void pack_many_kernel(const vkas_pack_desc* __
     else hi = mid;
   }
   const vkas_pack_desc d = descs[lo];
-  const long base = (long)((int)blockIdx.x - block_start[lo]) * PM_ELEMS;
+  const int lb = (int)blockIdx.x - block_start[lo];
+  if (d.kind == 0 && d.mode == 1) {
+    // dgrad layout [c][ky'][kx'][n] (taps rotated): a transpose of the (N, C*KH*KW) source.  Tile = 32 output rows x 64 output
+    // channels through LDS, so that the fp32 reads run along the source row and the 16-bit writes along n (element by
+    // element the reads of consecutive n are C*KH*KW floats apart: 0.5 ms per step for the 35 M parameters of config #3)
+    __shared__ float tile[64][33];
+    const int KHW = d.KH * d.KW, J = d.C * KHW, Jp = d.Cp * KHW;
+    const int tiles_n = (d.Np + 63) >> 6;
+    const int jo0 = (lb / tiles_n) * 32, n0 = (lb % tiles_n) * 64;
+    {
+      const int l = threadIdx.x & 31, r = threadIdx.x >> 5;
+      const int jo = jo0 + l;
+      const int c = jo / KHW, tap = KHW - 1 - (jo - c * KHW);
+      const bool j_ok = jo < Jp && c < d.C;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int nl = rr * 8 + r, n = n0 + nl;
+        tile[nl][l] = (j_ok && n < d.N) ? d.w[(long)n * J + c * KHW + tap] : 0.f;
+      }
+    }
+    __syncthreads();
+    const int l2 = threadIdx.x & 63, r2 = threadIdx.x >> 6;
+    const int n = n0 + l2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int row = k * 4 + r2, jo = jo0 + row;
+      if (jo < Jp && n < d.Np) {
+        const long o = (long)jo * d.Nt + d.n_off + n;
+        const float v = tile[l2][row];
+        if (d.dtype == VKAS_BF16) reinterpret_cast<bf16_t*>(d.out)[o] = from_f32<bf16_t>(v);
+        else if (d.dtype == VKAS_F16) reinterpret_cast<f16_t*>(d.out)[o] = from_f32<f16_t>(v);
+        else reinterpret_cast<float*>(d.out)[o] = v;
+      }
+    }
+    return;
+  }
+  const long base = (long)lb * PM_ELEMS;
 #pragma unroll
   for (int u = 0; u < PM_ELEMS / 256; ++u) {
     const long i = base + u * 256 + threadIdx.x;
@@ -260,6 +296,12 @@ extern "C" int vkas_pad_vector(const float* v, float* out, int n, int np, void* 
   pad_vector_kernel<<<(unsigned)vkas_cdiv(np, 256), 256, 0, vkas_stream(stream)>>>(v, out, n, np);
   VKAS_LAUNCH_CHECK("pad_vector");
   return VKAS_OK;
+}
+
+extern "C" int vkas_pack_many_blocks(const vkas_pack_desc* d) {
+  if (!d) return 0;
+  if (d->kind == 0 && d->mode == 1) return (int)(vkas_cdiv((long)d->Cp * d->KH * d->KW, 32) * vkas_cdiv(d->Np, 64));
+  return (int)vkas_cdiv(d->total, 2048);
 }
 
 extern "C" int vkas_pack_many(const vkas_pack_desc* descs, const int* block_start, int count, int total_blocks, void* stream) {

@@ -150,7 +150,7 @@ def refresh_packed_params():
         arr = (_lib.PackDesc * len(descs))(*descs)
         starts = [0]
         for d in descs:
-            starts.append(starts[-1] + (d.total + 2047) // 2048)
+            starts.append(starts[-1] + lib.vkas_pack_many_blocks(ctypes.byref(d)))
         dev = _PACK_CACHE[keys[0]][2].device
         table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         tab = (keys, table, torch.tensor(starts, dtype=torch.int32, device=dev), len(descs), starts[-1])
