@@ -206,6 +206,12 @@ def main():
         d_ms = pass_ms(lambda: step(rough, precise, lr=8e-4), n=max(2, min(args.steps, 5)))
         ops._POINT_SPARSE = True
         per_pass['dense_point_backward_ms_per_step'] = round(d_ms, 2)
+        # ... and with the opt-in label-point FORWARD of the regression heads on top (ops.HeadsAtPoints: their maps are then
+        # valid at the label points only - not the reference's module API, hence never the timed configuration)
+        lp = TwoPassStep(model, step.rough_loss_fn, step.precise_loss_fn, opt, reducer,
+                         merge_backbone=(args.schedule == 'merged'), label_point_forward=True)
+        l_ms = pass_ms(lambda: lp(rough, precise, lr=8e-4), n=max(2, min(args.steps, 5)))
+        per_pass['label_point_forward_ms_per_step'] = round(l_ms, 2)
 
     if rank == 0:
         print(f'[bench] {args.steps} steps in {elapsed:.3f} s on {world} GPU(s); host enqueue {enqueue:.3f} s; '

@@ -310,6 +310,12 @@ int vkas_points_gather_patches(const void* x, long ldx, int Cp, int B, int H, in
 int vkas_points_scatter3x3(const float* D, const int* pix, const int* map, long Mp, int B, int H, int W, int Cp, void* dx,
                            long lddx, int dtype, void* stream);
 
+/* (Mp, 8) fp32 rows <-> the (M, 8) projected-channel map of a head at the label points (opt-in label-point forward of
+ * the regression heads, ops.HeadsAtPoints): scatter writes the owner rows (pix[i] >= 0) to their pixels (duplicates
+ * and padding rows are skipped; dst is expected to be zero elsewhere); gather reads the owners' pixels and zero-fills the other rows. */
+int vkas_points_scatter_vec8(const float* src, const int* pix, long Mp, float* dst, void* stream);
+int vkas_points_gather_vec8(const float* src, const int* pix, long Mp, float* dst, void* stream);
+
 /* ---- all packed operands of a step in one launch ------------------------------------------------------------------- */
 /* One entry per packed image: kind 0 = vkas_pack_conv_weight(_slice) (mode, n_off, Nt, dtype as there; a plain weight has
  * n_off = 0, Nt = Np), kind 1 = vkas_pack_dw_weight (mode = flip; N, KH, KW, Np, n_off, Nt, dtype unused).  total =

@@ -512,3 +512,69 @@ def test_harness_two_epochs_end_to_end(tmp_path):
     step2 = TwoPassStep(model2, step.rough_loss_fn, step.precise_loss_fn, opt)
     r2, p2, l2 = evaluate(step2, loader(11, 2), dev, Metrics(MetricsTag, 2), 1, 1)
     assert abs(l2 - results[1].dev_loss) < 2e-3 * abs(results[1].dev_loss)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16], ids=['bf16'])
+def test_label_point_forward_matches_dense(dtype):
+    """Opt-in ops.HeadsAtPoints (TwoPassStep(label_point_forward=True)): the regression heads evaluated at the label points
+    only.  Their maps equal the dense maps AT the points (zeros elsewhere), the precise loss is the same, and every parameter
+    gradient is as close to an fp32 evaluation as the dense path's - duplicates, border points and adjacent points included."""
+    from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
+                                                           AdaptiveScalingNeckHeadType)
+    from vkit_ocr_model_adaptive_scaling_amd.loss_function import (
+        Box, AdaptiveScalingPreciseLossFunction, AdaptiveScalingPreciseLossFunctionConifg)
+    torch.manual_seed(5)
+    model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.TINY, AdaptiveScalingNeckHeadType.UPERNEXT),
+                            compute_dtype=dtype)
+    seed_module(model, 78, 0.05)
+    model.cuda().eval()
+    B, S, P = 2, 256, 24
+    H = W = S // 2
+    g = torch.Generator().manual_seed(4)
+    image = torch.randint(0, 256, (B, 3, S, S), generator=g).float().cuda()
+    py = torch.randint(0, H, (B, P), generator=g)
+    px = torch.randint(0, W, (B, P), generator=g)
+    py[0, :4] = torch.tensor([0, 0, H - 1, H - 1])
+    px[0, :4] = torch.tensor([0, W - 1, 0, W - 1])
+    py[0, 6:9], px[0, 6:9] = 40, 41
+    py[1, :4] = torch.tensor([60, 60, 61, 61])
+    px[1, :4] = torch.tensor([30, 31, 30, 31])
+    py, px = py.cuda(), px.cuda()
+    gt_score = torch.rand(B, H - 20, W - 20, generator=g).cuda()
+    gt_mask = (torch.rand(B, H - 20, W - 20, generator=g) > 0.3).float().cuda()
+    gt_off = (torch.rand(B, P, 2, generator=g) * 20 - 10).cuda()
+    gt_ang = torch.softmax(torch.randn(B, P, 4, generator=g), -1).cuda()
+    gt_dist = (torch.rand(B, P, 3, generator=g) * 10).cuda()
+    box = Box(up=10, down=H - 11, left=10, right=W - 11)
+    loss_fn = AdaptiveScalingPreciseLossFunction(AdaptiveScalingPreciseLossFunctionConifg())
+
+    def run(points):
+        model.zero_grad(set_to_none=True)
+        outs = model.forward_precise(image, label_points=points)
+        loss = loss_fn(None, *outs, gt_score, gt_mask, (H, W), box, py, px, gt_off, gt_ang, gt_dist)
+        loss.backward()
+        torch.cuda.synchronize()
+        return [o.detach() for o in outs], float(loss), {n: p.grad.clone() for n, p in model.named_parameters()
+                                                         if p.grad is not None}
+    o_dense, l_dense, g_dense = run(None)
+    o_pts, l_pts, g_pts = run((py, px))
+    bi = torch.arange(B, device='cuda')[:, None]
+    assert torch.equal(o_pts[0], o_dense[0])                 # the probability head is the same dense kernel
+    for a, b in zip(o_pts[1:], o_dense[1:]):
+        at_a, at_b = a[bi, :, py, px], b[bi, :, py, px]      # (B, P, C): the values the loss reads
+        assert rel_err(at_a, at_b) < 5e-3
+        mask = torch.ones_like(a, dtype=torch.bool)
+        mask[bi, :, py, px] = False
+        ref_off = torch.nn.functional.softplus(torch.zeros(())).item() if a is o_pts[3] else 0.0
+        assert float((a[mask] - ref_off).abs().max()) < 1e-6  # nothing (softplus(0) for the distance head) off the points
+    assert abs(l_pts - l_dense) < 2e-3 * abs(l_dense)
+    assert set(g_pts) == set(g_dense)
+    model.set_compute_dtype(torch.float32)
+    _, _, g_ref = run(None)
+    model.set_compute_dtype(dtype)
+    e_p = {n: rel_err(g_pts[n], g_ref[n]) for n in g_ref}
+    e_d = {n: rel_err(g_dense[n], g_ref[n]) for n in g_ref}
+    print('label-point forward vs fp32: worst', max(e_p.values()), 'dense path', max(e_d.values()))
+    assert max(e_p.values()) < GRAD_TOL[dtype], max(e_p, key=e_p.get)
+    worse = {n: (e_p[n], e_d[n]) for n in g_ref if e_p[n] > 1.5 * e_d[n] + 3e-3}
+    assert not worse, worse

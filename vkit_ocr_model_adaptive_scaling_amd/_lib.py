@@ -124,6 +124,8 @@ _SIGS = {
     'vkas_points_gather_rows': (c_int, [_P, c_long, c_int, c_int, _P, _P, c_int, c_long, _P, c_long, _P, _P, _P, c_int, _P]),
     'vkas_points_gather_patches': (c_int, [_P, c_long, c_int, c_int, c_int, c_int, _P, c_long, _P, c_int, _P]),
     'vkas_points_scatter3x3': (c_int, [_P, _P, _P, c_long, c_int, c_int, c_int, c_int, _P, c_long, c_int, _P]),
+    'vkas_points_scatter_vec8': (c_int, [_P, _P, c_long, _P, _P]),
+    'vkas_points_gather_vec8': (c_int, [_P, _P, c_long, _P, _P]),
     'vkas_pack_many': (c_int, [_P, _P, c_int, c_int, _P]),
     'vkas_pack_many_blocks': (c_int, [_P]),
     'vkas_rough_postprocess': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P]),

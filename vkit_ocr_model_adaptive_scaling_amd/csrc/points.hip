@@ -145,7 +145,43 @@ __global__ __launch_bounds__(64) void points_scatter3x3_kernel(const float* __re
   }
 }
 
+// (rows, 8) fp32 vectors <-> the (M, 8) projected-channel maps of a head, at the label points
+__global__ __launch_bounds__(256) void points_scatter_vec8_kernel(const float* __restrict__ src, const int* __restrict__ pix,
+                                                                  long Mp, float* __restrict__ dst) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;  // (row, half)
+  const long i = t >> 1;
+  if (i >= Mp) return;
+  const int p = pix[i];
+  if (p < 0) return;  // padding rows, and duplicates of a pixel: its owner's row is the one computed from the real patch
+  reinterpret_cast<float4*>(dst + (long)p * 8)[t & 1] = reinterpret_cast<const float4*>(src + i * 8)[t & 1];
+}
+
+__global__ __launch_bounds__(256) void points_gather_vec8_kernel(const float* __restrict__ src, const int* __restrict__ pix,
+                                                                 long Mp, float* __restrict__ dst) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long i = t >> 1;
+  if (i >= Mp) return;
+  const int p = pix[i];
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p >= 0) v = reinterpret_cast<const float4*>(src + (long)p * 8)[t & 1];  // a pixel's gradient is taken once (its owner)
+  reinterpret_cast<float4*>(dst + i * 8)[t & 1] = v;
+}
+
 }  // namespace
+
+extern "C" int vkas_points_scatter_vec8(const float* src, const int* pix, long Mp, float* dst, void* stream) {
+  VKAS_CHECK(src && pix && dst && Mp > 0 && vkas_aligned16(src) && vkas_aligned16(dst), "vkas_points_scatter_vec8: bad arguments");
+  points_scatter_vec8_kernel<<<(unsigned)vkas_cdiv(2 * Mp, 256), 256, 0, vkas_stream(stream)>>>(src, pix, Mp, dst);
+  VKAS_LAUNCH_CHECK("points_scatter_vec8");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_points_gather_vec8(const float* src, const int* pix, long Mp, float* dst, void* stream) {
+  VKAS_CHECK(src && pix && dst && Mp > 0 && vkas_aligned16(src) && vkas_aligned16(dst), "vkas_points_gather_vec8: bad arguments");
+  points_gather_vec8_kernel<<<(unsigned)vkas_cdiv(2 * Mp, 256), 256, 0, vkas_stream(stream)>>>(src, pix, Mp, dst);
+  VKAS_LAUNCH_CHECK("points_gather_vec8");
+  return VKAS_OK;
+}
 
 extern "C" int vkas_points_prepare(const long* py, const long* px, int B, int P, int H, int W, int* map, int* pix, long Mp,
                                    void* stream) {

@@ -92,7 +92,7 @@ class AdaptiveScaling(nn.Module):
     def set_compute_dtype(self, dtype: torch.dtype):
         return set_compute_dtype(self, dtype)
 
-    def _run_heads(self, neck_feature: torch.Tensor, heads: Sequence[nn.Module]):
+    def _run_heads(self, neck_feature: torch.Tensor, heads: Sequence[nn.Module], label_points=None, n_dense: int = 1):
         """All heads of a pass read the same neck feature (adaptive_scaling.py:150-152,163-170): upsample it once and
         run their 3x3 convolutions as ONE implicit GEMM (output channels of the heads side by side, each padded to a
         multiple of 8), then per-head LayerNorm+GELU on channel slices, projection, NCHW, Softplus."""
@@ -105,8 +105,16 @@ class AdaptiveScaling(nn.Module):
             fused = []
             for cv, nm, proj in zip(convs, norms, projs):
                 fused.extend([cv.weight, cv.bias, nm.weight, nm.bias, proj.weight, proj.bias])
+            if label_points is not None and torch.is_grad_enabled() and 0 < n_dense < len(heads):
+                # opt-in (TwoPassStep(label_point_forward=True)): the heads behind the first n_dense are evaluated at the
+                # label points only - their maps are zero elsewhere, which is all a label-point loss reads
+                py, px = label_points
+                ys = (ops.HeadsFused.apply(up, True, *fused[:6 * n_dense])
+                      + ops.HeadsAtPoints.apply(up, py, px, *fused[6 * n_dense:]))
+            else:
+                ys = ops.HeadsFused.apply(up, torch.is_grad_enabled(), *fused)
             outs = []
-            for h, hp, y in zip(heads, plain, ops.HeadsFused.apply(up, torch.is_grad_enabled(), *fused)):
+            for h, hp, y in zip(heads, plain, ys):
                 y = ops.ToNchw.apply(y, hp.out_channels)
                 outs.append(h[1](y) if isinstance(h, nn.Sequential) else y)
             return tuple(outs)
@@ -133,15 +141,17 @@ class AdaptiveScaling(nn.Module):
         neck = self.rough_neck.forward_act(feats)
         return self._run_heads(neck, (self.rough_char_mask_head, self.rough_char_height_head))  # type: ignore
 
-    def forward_precise(self, x: torch.Tensor, drop_masks=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-        """adaptive_scaling.py:156-177"""
+    def forward_precise(self, x: torch.Tensor, drop_masks=None,
+                        label_points=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """adaptive_scaling.py:156-177.  ``label_points`` = (y, x) (B,P) int64 is an extension for training steps only (see
+        ops.HeadsAtPoints): the offset / angle / distance maps are then valid at those points and zero elsewhere."""
         feats = self.backbone.forward_act(x, drop_masks)
         neck = self.precise_neck.forward_act(feats)
         return self._run_heads(neck, (self.precise_char_prob_head, self.precise_char_up_left_corner_offset_head,
                                       self.precise_char_corner_angle_head,
-                                      self.precise_char_corner_distance_head))  # type: ignore
+                                      self.precise_char_corner_distance_head), label_points)  # type: ignore
 
-    def forward_both(self, x_rough: torch.Tensor, x_precise: torch.Tensor, drop_masks=None):
+    def forward_both(self, x_rough: torch.Tensor, x_precise: torch.Tensor, drop_masks=None, precise_label_points=None):
         """forward_rough(x_rough) and forward_precise(x_precise) with ONE backbone pass over the concatenated batch.
         The reference's step (train.py:397-478) runs the two passes back to back and lets the gradients accumulate;
         no layer couples samples of a batch (LayerNorm is per pixel, stochastic depth per sample), so the outputs are
@@ -154,7 +164,8 @@ class AdaptiveScaling(nn.Module):
                                 (self.rough_char_mask_head, self.rough_char_height_head))
         precise = self._run_heads(self.precise_neck.forward_act([h[1] for h in halves]),
                                   (self.precise_char_prob_head, self.precise_char_up_left_corner_offset_head,
-                                   self.precise_char_corner_angle_head, self.precise_char_corner_distance_head))
+                                   self.precise_char_corner_angle_head, self.precise_char_corner_distance_head),
+                                  precise_label_points)
         return rough, precise
 
     # ---- gradient inspection helpers (adaptive_scaling.py:179-237) ---------------------------------------

@@ -920,6 +920,149 @@ class HeadsFused(Function):
         return (dx, None, *grads)
 
 
+class HeadsAtPoints(Function):
+    """Opt-in companion of HeadsFused for a TRAINING step: heads whose outputs the loss reads at the label points only
+    (the precise pass's offset / angle / distance heads, loss_function/adaptive_scaling.py:167-179,235-262) evaluated AT
+    those points only - the 3x3 patches at the (B, P) points are gathered and conv -> LayerNorm -> GELU -> Linear runs on
+    B*P rows instead of B*H*W.  The returned (B,H,W,8) maps hold the heads' true outputs at the label points and zeros
+    elsewhere, so this is NOT the module API of the reference (forward_precise returns dense maps): it exists for
+    TwoPassStep(label_point_forward=True) and is never the default.  Losses and parameter gradients are those of the dense
+    evaluation (the loss reads nothing else; tests/test_gpu_model.py::test_label_point_forward_matches_dense).
+
+    inputs: x (B,H,W,Cp), py, px (B,P) int64, then per head the six parameters of HeadsFused."""
+
+    @staticmethod
+    def forward(ctx, x, py, px, *params):
+        _require_cuda(x, py, px, params[0])
+        x = as_act(x)
+        if x.dtype not in _MFMA_DTYPES:
+            raise ValueError('HeadsAtPoints: 16-bit activations only')
+        n_heads = len(params) // 6
+        ws, bs = params[0::6], params[1::6]
+        gammas, betas, wps, bps = params[2::6], params[3::6], params[4::6], params[5::6]
+        cs = [g.numel() for g in gammas]
+        ocs = [w.shape[0] for w in wps]
+        nps = [rup8(c) for c in cs]
+        Ns = sum(nps)
+        B, H, W, Cp = x.shape
+        C = ws[0].shape[1]
+        assert all(tuple(w.shape) == (c, C, 3, 3) for w, c in zip(ws, cs)) and Cp == rup8(C)
+        if n_heads > 4 or max(ocs) > 4 or max(nps) > 512:
+            raise ValueError('HeadsAtPoints: at most 4 heads of at most 512 channels and 4 outputs')
+        py, px = py.contiguous().long(), px.contiguous().long()
+        if py.dim() != 2 or py.shape[0] != B or px.shape != py.shape or py.shape[1] == 0:
+            raise ValueError(f'HeadsAtPoints: label points must be (B={B}, P > 0)')
+        P = py.shape[1]
+        M, K = B * H * W, 9 * Cp
+        Mp = -(-(B * P) // 64) * 64
+        pw = max(nps)
+        dev = x.device
+        scratch = torch.empty((M + Mp,), dtype=torch.int32, device=dev)
+        pmap, pix = scratch[:M], scratch[M:]
+        check(lib.vkas_points_prepare(_p(py), _p(px), B, P, H, W, _p(pmap), _p(pix), Mp, _stream()), 'points_prepare')
+        xs = new_act(1, 1, Mp, K, x)
+        check(lib.vkas_points_gather_patches(_p(x), act_ld(x), Cp, B, H, W, _p(pix), Mp, _p(xs), _dt(x), _stream()),
+              'points_gather_patches')
+
+        def build_hp():
+            t = torch.empty((n_heads, 6 * pw + 8), dtype=_FLOAT, device=dev)
+            for h in range(n_heads):
+                check(lib.vkas_pack_head_params(_p(gammas[h].contiguous()), _p(betas[h].contiguous()),
+                                                _p(wps[h].contiguous()), _p(bps[h].contiguous()), cs[h], ocs[h], pw,
+                                                _p(t[h]), _stream()), 'pack_head_params')
+            return t
+
+        def build_bias():
+            t = torch.zeros((Ns,), dtype=_FLOAT, device=dev)
+            off = 0
+            for b, c, np_ in zip(bs, cs, nps):
+                t[off:off + c].copy_(b.detach())
+                off += np_
+            return t
+        hp = _cached_pack_multi(list(gammas) + list(betas) + list(wps) + list(bps), ('head_params', pw), build_hp)
+        b_cat = _cached_pack_multi(list(bs), ('head_bias', tuple(nps)), build_bias)
+        Wf = pack_head_weights(ws, nps, Cp, 0, x.dtype)
+        zs = new_act(1, 1, Mp, Ns, x)
+        g1 = _geom(1, 1, Mp, 1, Mp, K, K, 1, 1, 1, 0)
+        conv_gemm(xs, g1, Wf, Ns, zs, _lib.EPI_NONE, bias=b_cat, nk=(sum(cs), C * 9))
+        fbuf = torch.empty((n_heads * Mp * 10,), dtype=_FLOAT, device=dev)
+        stats_s, proj_s = fbuf[:n_heads * Mp * 2], fbuf[n_heads * Mp * 2:]
+        head = _lib.HeadDesc()
+        head.n_heads, head.pw = n_heads, pw
+        off = 0
+        for h in range(n_heads):
+            head.n0[h], head.np[h], head.c[h], head.oc[h] = off, nps[h], cs[h], ocs[h]
+            off += nps[h]
+        head.params, head.stats, head.proj = hp.data_ptr(), stats_s.data_ptr(), proj_s.data_ptr()
+        check(lib.vkas_head_tail_fwd(_p(zs), Ns, ctypes.byref(head), Mp, _dt(x), _stream()), 'head_tail_fwd')
+        proj = torch.zeros((n_heads, B, H, W, 8), dtype=_FLOAT, device=dev)
+        for h in range(n_heads):
+            check(lib.vkas_points_scatter_vec8(ctypes.c_void_p(proj_s.data_ptr() + h * Mp * 32), _p(pix), Mp, _p(proj[h]),
+                                               _stream()), 'points_scatter_vec8')
+        ctx.save_for_backward(xs, zs, stats_s, hp, scratch, *ws, *bs)
+        ctx.meta = (cs, ocs, nps, pw, C, (B, H, W, Cp), P, Mp, x.dtype)
+        return tuple(proj[h] for h in range(n_heads))
+
+    @staticmethod
+    def backward(ctx, *dprojs):
+        cs, ocs, nps, pw, C, (B, H, W, Cp), P, Mp, dtype = ctx.meta
+        n_heads = len(cs)
+        saved = ctx.saved_tensors
+        xs, zs, stats_s, hp, scratch = saved[:5]
+        ws, bs = saved[5:5 + n_heads], saved[5 + n_heads:5 + 2 * n_heads]
+        M, K = B * H * W, 9 * Cp
+        Ns = sum(nps)
+        dev = xs.device
+        pmap, pix = scratch[:M], scratch[M:]
+        PS = 6 * pw + 8
+        offs = [sum(nps[:h]) for h in range(n_heads + 1)]
+        dproj_s = torch.empty((n_heads, Mp, 8), dtype=_FLOAT, device=dev)
+        for h in range(n_heads):
+            if dprojs[h] is None:
+                dproj_s[h].zero_()
+            else:
+                check(lib.vkas_points_gather_vec8(_p(dprojs[h].contiguous().float()), _p(pix), Mp, _p(dproj_s[h]), _stream()),
+                      'points_gather_vec8')
+        dparams = torch.empty((n_heads, PS), dtype=_FLOAT, device=dev)
+        head = _lib.HeadDesc()
+        head.n_heads, head.pw = n_heads, pw
+        ptrs = (ctypes.c_void_p * 4)()
+        for h in range(n_heads):
+            head.n0[h], head.np[h], head.c[h], head.oc[h] = offs[h], nps[h], cs[h], ocs[h]
+            ptrs[h] = dproj_s[h].data_ptr()
+        head.params, head.stats, head.proj = hp.data_ptr(), stats_s.data_ptr(), None
+        nbytes = lib.vkas_head_tail_bwd_ws_bytes(Mp, pw)
+        ws_buf = _ws(nbytes, dev)
+        dzs = new_act(1, 1, Mp, Ns, xs)
+        check(lib.vkas_head_tail_bwd(_p(zs), Ns, ctypes.byref(head), ptrs, _p(dzs), Ns, _p(dparams), _p(ws_buf), nbytes, Mp,
+                                     _dtc(dtype), _stream()), 'head_tail_bwd')
+        g1 = _geom(1, 1, Mp, 1, Mp, K, K, 1, 1, 1, 0)
+        gwp, gbp = conv_wgrad(xs, g1, dzs, Ns, nk=(sum(cs), C * 9), with_bias=True)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            Wf = pack_head_weights(ws, nps, Cp, 0, dtype).view(1, 1, Ns, K)
+            dzt = dzs.view(Mp, Ns).t().contiguous().view(1, 1, Ns, Mp)
+            g3 = _geom(1, 1, Ns, 1, Ns, K, K, 1, 1, 1, 0)
+            D = conv_wgrad(Wf, g3, dzt, Mp, nk=(B * P, C * 9))
+            dx = torch.zeros((B, H, W, Cp), dtype=dtype, device=dev)
+            check(lib.vkas_points_scatter3x3(_p(D), _p(pix), _p(pmap), Mp, B, H, W, Cp, _p(dx), Cp, _dtc(dtype), _stream()),
+                  'points_scatter3x3')
+        grads = []
+        for h in range(n_heads):
+            gslice = gwp[offs[h] * K:offs[h + 1] * K]
+            sw = grad_sink(ws[h])
+            if sw is not None:
+                unpack_wgrad(gslice, (cs[h], C, 3, 3), nps[h], Cp, into=ws[h].grad)
+                sw[0].grad_delivered(sw[1])
+                gw = None
+            else:
+                gw = unpack_wgrad(gslice, (cs[h], C, 3, 3), nps[h], Cp)
+            d = dparams[h]
+            grads.extend([gw, gbp[offs[h]:offs[h] + cs[h]], d[:cs[h]], d[pw:pw + cs[h]],
+                          d[2 * pw:6 * pw].view(4, pw)[:ocs[h], :cs[h]], d[6 * pw:6 * pw + ocs[h]]])
+        return (dx, None, None, *grads)
+
+
 _POINT_SPARSE = os.environ.get('VKAS_POINT_SPARSE_BWD', '1') != '0'
 
 

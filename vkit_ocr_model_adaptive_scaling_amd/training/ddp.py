@@ -115,7 +115,7 @@ class TwoPassStep:
     forward/loss/backward (gradients accumulate), gradient all-reduce, global-norm clip, AdamW."""
 
     def __init__(self, model, rough_loss_fn, precise_loss_fn, optimizer, reducer: Optional[BucketedGradReducer] = None,
-                 merge_backbone: bool = False):
+                 merge_backbone: bool = False, label_point_forward: bool = False):
         """merge_backbone: run the backbone once over both batches (model.forward_both) and back-propagate
         rough_loss + precise_loss in one backward: the same gradients as the two accumulating passes (the sum is taken
         in a different order), half the backbone launches."""
@@ -124,6 +124,9 @@ class TwoPassStep:
         self.world = reducer.world_size if reducer is not None else 1
         self._backbone_buckets = [b for b in (reducer.buckets if reducer else {}) if b.startswith('backbone')]
         self.merge_backbone = merge_backbone
+        # opt-in, NOT the reference's module API: the regression heads' forward at the label points only (the precise loss
+        # reads nothing else of them); same losses and gradients, see ops.HeadsAtPoints
+        self.label_point_forward = label_point_forward
 
     def _rough_loss(self, outs, b, scale):
         mask, height = outs
@@ -140,8 +143,11 @@ class TwoPassStep:
     def __call__(self, rough_batch: dict, precise_batch: dict, lr: Optional[float] = None):
         scale = 0.5 / self.world  # train.py:413,451 (loss / 2), averaged over ranks
         r = self.reducer
+        pts = ((precise_batch['downsampled_label_point_y'], precise_batch['downsampled_label_point_x'])
+               if self.label_point_forward else None)
         if self.merge_backbone:
-            rough_out, precise_out = self.model.forward_both(rough_batch['image'], precise_batch['image'])
+            rough_out, precise_out = self.model.forward_both(rough_batch['image'], precise_batch['image'],
+                                                             precise_label_points=pts)
             rough_loss = self._rough_loss(rough_out, rough_batch, scale)
             precise_loss = self._precise_loss(precise_out, precise_batch, scale)
             if r is not None:
@@ -152,7 +158,8 @@ class TwoPassStep:
             if r is not None:
                 r.arm(['rough'])
             rough_loss.backward()
-            precise_loss = self._precise_loss(self.model.forward_precise(precise_batch['image']), precise_batch, scale)
+            precise_loss = self._precise_loss(self.model.forward_precise(precise_batch['image'], label_points=pts),
+                                              precise_batch, scale)
             if r is not None:
                 r.arm(['precise'] + self._backbone_buckets)
             precise_loss.backward()
