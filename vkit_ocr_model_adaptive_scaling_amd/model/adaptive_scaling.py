@@ -4,6 +4,8 @@ from enum import Enum, unique
 from typing import Dict, Mapping, Optional, Sequence, Tuple
 
 import attrs
+import os
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -47,6 +49,16 @@ class _SoftplusSlot(nn.Module):
 
     def forward(self, x):
         return ops.Softplus.apply(x)
+
+
+_TWO_STREAMS = os.environ.get('VKAS_TWO_STREAMS', '0') == '1'
+_SIDE = {}
+
+
+def _side_stream(device):
+    if device not in _SIDE:
+        _SIDE[device] = torch.cuda.Stream(device=device)
+    return _SIDE[device]
 
 
 _BACKBONES = {
@@ -160,12 +172,28 @@ class AdaptiveScaling(nn.Module):
         b0 = x_rough.shape[0]
         feats = self.backbone.forward_act(torch.cat([x_rough, x_precise], 0), drop_masks)
         halves = [ops.SplitBatch.apply(f, b0) for f in feats]
-        rough = self._run_heads(self.rough_neck.forward_act([h[0] for h in halves]),
-                                (self.rough_char_mask_head, self.rough_char_height_head))
-        precise = self._run_heads(self.precise_neck.forward_act([h[1] for h in halves]),
-                                  (self.precise_char_prob_head, self.precise_char_up_left_corner_offset_head,
-                                   self.precise_char_corner_angle_head, self.precise_char_corner_distance_head),
-                                  precise_label_points)
+
+        def rough_branch():
+            return self._run_heads(self.rough_neck.forward_act([h[0] for h in halves]),
+                                   (self.rough_char_mask_head, self.rough_char_height_head))
+
+        def precise_branch():
+            return self._run_heads(self.precise_neck.forward_act([h[1] for h in halves]),
+                                   (self.precise_char_prob_head, self.precise_char_up_left_corner_offset_head,
+                                    self.precise_char_corner_angle_head, self.precise_char_corner_distance_head),
+                                   precise_label_points)
+        if not _TWO_STREAMS:
+            return rough_branch(), precise_branch()
+        # experiment (VKAS_TWO_STREAMS=1): the two neck + head branches are independent until the losses are summed
+        main = torch.cuda.current_stream()
+        side = _side_stream(x_rough.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            precise = precise_branch()
+        rough = rough_branch()
+        main.wait_stream(side)
+        for t in precise:
+            t.record_stream(main)
         return rough, precise
 
     # ---- gradient inspection helpers (adaptive_scaling.py:179-237) ---------------------------------------
