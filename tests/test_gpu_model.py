@@ -459,9 +459,19 @@ def test_batched_repack_matches_lazy_packs():
     assert set(ops._PACK_PLAN) == set(batched)
     for k, img in batched.items():
         assert torch.equal(ops._PACK_CACHE[k][2], img), k[1]
-    # and a second refresh re-uses the uploaded table
-    table = ops._PACK_TABLE[0][1].data_ptr()
+    # the images were re-allocated by the lazy rebuild: the next refresh must upload a new table (same keys, new buffers) ...
+    old_sig = ops._PACK_TABLE[0][0]
+    fb.flat_param.add_(torch.randn_like(fb.flat_param) * 0.01)
     ops.refresh_packed_params()
+    assert ops._PACK_TABLE[0][0] != old_sig
+    again = {k: ops._PACK_CACHE[k][2].clone() for k in ops._PACK_PLAN}
+    ops.invalidate_packed_params()
+    step()
+    for k, img in again.items():
+        assert torch.equal(ops._PACK_CACHE[k][2], img), k[1]
+    # ... and refreshes without re-allocation re-use it
+    ops.refresh_packed_params()
+    table = ops._PACK_TABLE[0][1].data_ptr()
     ops.refresh_packed_params()
     assert ops._PACK_TABLE[0][1].data_ptr() == table
 

@@ -107,7 +107,7 @@ _PACK_EPOCH = [0]
 # Recipes of the cached images that one vkas_pack_many launch can rebuild (conv / depthwise weights of leaf parameters):
 # cache key -> (list of _lib.PackDesc, parameters as weak references, their data pointers when the recipe was recorded)
 _PACK_PLAN = {}
-_PACK_TABLE = [None]  # (plan keys, device table of descriptors, device block starts, entry count, workgroups)
+_PACK_TABLE = [None]  # ((source, image) pointers of all entries, device descriptor table, device block starts, entries, workgroups)
 
 
 def invalidate_packed_params():
@@ -144,16 +144,19 @@ def refresh_packed_params():
     if not live:
         return
     keys = tuple(live)
+    descs = [d for k in keys for d in live[k][0]]
+    # the uploaded table is valid while the same entries point at the same buffers (an invalidate + lazy rebuild gives the same
+    # keys new images)
+    sig = tuple((d.w, d.out) for d in descs)
     tab = _PACK_TABLE[0]
-    if tab is None or tab[0] != keys:
-        descs = [d for k in keys for d in live[k][0]]
+    if tab is None or tab[0] != sig:
         arr = (_lib.PackDesc * len(descs))(*descs)
         starts = [0]
         for d in descs:
             starts.append(starts[-1] + lib.vkas_pack_many_blocks(ctypes.byref(d)))
         dev = _PACK_CACHE[keys[0]][2].device
         table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-        tab = (keys, table, torch.tensor(starts, dtype=torch.int32, device=dev), len(descs), starts[-1])
+        tab = (sig, table, torch.tensor(starts, dtype=torch.int32, device=dev), len(descs), starts[-1])
         _PACK_TABLE[0] = tab
     check(lib.vkas_pack_many(_p(tab[1]), _p(tab[2]), tab[3], tab[4], _stream()), 'pack_many')
     for k in keys:
