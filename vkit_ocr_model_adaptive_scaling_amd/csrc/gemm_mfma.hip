@@ -1143,6 +1143,19 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const elem_t* _
   const unsigned lds_base = (unsigned)(uintptr_t)(wg_lds_ptr)lds;
 
   const int grp = wave >> 2;
+#if defined(VKAS_TRACE) && !defined(VKAS_MFMA_F16)
+  // per (workgroup, wave group) sums of s_memtime cycles: 0 fragment reads (+ lgkmcnt), 1 DMA issue, 2 retire (vmcnt),
+  // 3 barrier after READ, 4 MFMA phase, 5 retire of group 0, 6 barrier after MFMA, 7 chunks   (profiles/trace_wgrad.py)
+  unsigned long long tw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tw_last = __builtin_readcyclecounter();
+#define WG_TR(i)                                                  \
+  do {                                                            \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    tw[i] += now_ - tw_last;                                      \
+    tw_last = now_;                                               \
+  } while (0)
+#else
+#define WG_TR(i)
+#endif
   if (nchunks > 0) issue_chunk(0);
   if (nchunks > 1) issue_chunk(1);
   if (nchunks > 2) issue_chunk(2);
@@ -1167,12 +1180,20 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const elem_t* _
       fx[1][j] = wg_frag2(a + 8192u, bufb + x_last[j]);
     }
     asm volatile("" ::: "memory");
+#if defined(VKAS_TRACE) && !defined(VKAS_MFMA_F16)
+    if (t == 0) tw_last = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    WG_TR(0);
     const bool issued = t + 3 < nchunks;
     if constexpr ((ABL & 1) == 0) {
       if (issued) issue_chunk((t + 3) & 3);
     }
+    WG_TR(1);
     // chunks t+2 and t+3 (2 x 5 instructions, 2 x 4 for the waves without a second dy instruction) may stay in flight;
-    // near the end of the split fewer were issued
+    // near the end of the split fewer were issued.  (Issuing chunk t+3 between the two K halves of the MFMA phase instead
+    // - the READ phase is the longer one: fragment reads 860 + DMA issue 400 cycles against 850, profiles/trace_wgrad.py -
+    // was measured in round 2: the issue cost moves with it, the MFMA phase grows to 1190 cycles, no gain.)
     auto retire = [&]() {
       if (t + 3 >= nchunks) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (d_count == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
@@ -1180,8 +1201,10 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const elem_t* _
     };
     if (grp == 1) retire();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    WG_TR(2);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    WG_TR(3);
     // ---- MFMA phase
     if constexpr ((ABL & 16) != 0) {
 #pragma unroll
@@ -1210,11 +1233,20 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const elem_t* _
 #pragma unroll
           for (int q = 0; q < 8; ++q) bsum[i] += (float)fd[h][i][q];
     }
+    WG_TR(4);
     if (grp == 0) retire();
+    WG_TR(5);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    WG_TR(6);
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();  // group 1's last MFMA phase: every wave passes the same number of barriers
+#if defined(VKAS_TRACE) && !defined(VKAS_MFMA_F16)
+  if ((tid & 255) == 0 && blockIdx.x < 32768) {
+    tw[7] = (unsigned long long)nchunks;
+    for (int i = 0; i < 8; ++i) vkas_trace_buf[(blockIdx.x * 2 + grp) * 8 + i] = tw[i];
+  }
+#endif
 
   // D[row = n_local][col = k_local]: lane holds col = lane&15, rows (lane>>4)*4 + r
 #pragma unroll
