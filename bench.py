@@ -91,6 +91,202 @@ def cpu_baseline(hw, seed):
                       f'fwd+loss+bwd both passes, no optimizer): {dt:.1f} s'}
 
 
+def roofline_from_timer(timer, elapsed, steps, use_pmc=False, mfma_peak=MFMA_BF16_DENSE_PEAK_TFLOPS):
+    """``roofline`` object of the JSON line from the per-launch HIP-event records of the timed region (ops.LaunchTimer).
+    Dominant kernel = the instantiation with the largest share of the timed region.  Its roof is whichever of the two bounds
+    is tighter for the launches it ran: algorithmic flops / dense 16-bit MFMA peak or algorithmic bytes / HBM peak (the
+    short-K layer GEMMs are HBM-bound, the 3x3 head convolutions MFMA-bound)."""
+    summ = timer.summary()
+    if not summ:
+        return {'bound': 'mfma', 'kernel': 'none', 'achieved': 0.0, 'peak': mfma_peak, 'unit': 'TFLOP/s', 'frac': 0.0,
+                'traffic': None}
+    dom = max(summ, key=lambda k: summ[k]['ms'])
+
+    def stats(k):
+        fl = sum(r[3] for r in timer.records if r[0] == k)
+        nb = sum(r[7] for r in timer.records if r[0] == k)
+        ms_ = summ[k]['ms']
+        t_mfma, t_hbm = fl / (mfma_peak * 1e12), nb / (HBM_PEAK_GBS * 1e9)
+        bound = 'mfma' if t_mfma >= t_hbm else 'hbm'
+        ach = fl / (ms_ * 1e-3) / 1e12 if bound == 'mfma' else nb / (ms_ * 1e-3) / 1e9
+        peak = mfma_peak if bound == 'mfma' else HBM_PEAK_GBS
+        return {'bound': bound, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
+                'frac': round(ach / peak, 4), 'launches_per_step': summ[k]['launches'] / max(steps, 1),
+                'avg_launch_ms': round(ms_ / max(summ[k]['launches'], 1), 4),
+                'algorithmic_flops_per_launch': fl / max(summ[k]['launches'], 1),
+                'algorithmic_bytes_per_launch': nb / max(summ[k]['launches'], 1),
+                'share_of_step_time': round(ms_ / (1000.0 * elapsed), 3)}
+
+    traffic, traffic_source = None, None
+    pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if use_pmc and os.path.exists(pmc_path):  # per-launch HBM bytes from the rocprofv3 --pmc passes of this command
+        pmc_all = json.load(open(pmc_path))
+        pmc = pmc_all.get(dom)
+        if pmc:  # measured by a separate rocprofv3 run of this command, not in this run: say which one
+            traffic = pmc['bytes_per_launch']
+            traffic_source = pmc_all.get('_meta', {}).get('source', 'profiles/pmc_traffic.json')
+    is_gemm = lambda k: k.startswith(('gemm_', 'conv3x3_', 'mlp_chain_'))  # the depthwise / resize launches are timed too (HBM roofs)
+    all_gemm_flops = sum(v['flops'] for k, v in summ.items() if is_gemm(k))
+    all_gemm_ms = sum(v['ms'] for k, v in summ.items() if is_gemm(k))
+    roof = stats(dom)
+    return {'bound': roof['bound'], 'kernel': dom, 'achieved': roof['achieved'], 'peak': roof['peak'],
+            'unit': roof['unit'], 'frac': roof['frac'], 'traffic': traffic, 'traffic_source': traffic_source,
+            **{k: v for k, v in roof.items() if k not in ('bound', 'achieved', 'peak', 'unit', 'frac')},
+            'all_gemm_kernels': {'tflops': round(all_gemm_flops / (all_gemm_ms * 1e-3) / 1e12, 2) if all_gemm_ms > 0 else 0.0,
+                                 'share_of_step_time': round(all_gemm_ms / (1000.0 * elapsed), 3)},
+            'other_kernels': {k: {kk: vv for kk, vv in stats(k).items()
+                                  if kk in ('bound', 'achieved', 'unit', 'frac', 'avg_launch_ms', 'share_of_step_time')}
+                              for k in summ if k != dom}}
+
+
+CONFIG5_SHAPES = [(h, w) for h in range(1536, 2049, 128) for w in range(1024, 1537, 128)]  # long edge 1536..2048, x32
+
+
+def config5_shape_sequence(n, seed):
+    """Seeded sequence of (H, W) for BASELINE.json configs[4]: long edge 1536..2048, short edge 1024..1536, multiples of 32
+    (inferencing/adaptive_scaling.py:95-107 pads every page to x32); the largest shape 2048 x 1536 always occurs."""
+    import random
+    rnd = random.Random(seed)
+    seq = [rnd.choice(CONFIG5_SHAPES) for _ in range(n)]
+    if n > 0 and (2048, 1536) not in seq:
+        seq[rnd.randrange(n)] = (2048, 1536)
+    return seq
+
+
+def run_forward_config(args, world, rank, device, dist):
+    """BASELINE.json configs[1] (--config 2: ConvNeXt-Tiny backbone forward, 640 x 640, bf16, batch 4) and configs[4]
+    (--config 5: ConvNeXt-Base + UPerNext, fp16, no-grad inference of both passes + the device post-processing over a seeded
+    SEQUENCE of page shapes, B = 1; N > 1: independent replicas, each rank its own pages).  One JSON line like config 3's."""
+    import torch
+    from vkit_ocr_model_adaptive_scaling_amd import ops
+    from vkit_ocr_model_adaptive_scaling_amd._lib import lib, check
+    from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
+                                                           AdaptiveScalingNeckHeadType, ConvNext, set_compute_dtype)
+    import ctypes
+    torch.manual_seed(1234)
+    g = torch.Generator(device='cpu').manual_seed(1337 + rank)
+    if args.config == 2:
+        dtype = torch.bfloat16
+        model = set_compute_dtype(ConvNext.create_tiny().to(device).eval(), dtype)
+        B = 4
+        x = torch.randint(0, 256, (B, 3, 640, 640), generator=g).float().to(device)
+        shapes = [(640, 640)] * (args.steps + args.warmup)
+
+        def step(i):
+            return model.forward_act(x)
+        workload = 'ConvNeXt-Tiny backbone forward 640x640, batch 4 per GPU, no grad (BASELINE.json configs[1])'
+        dt_name = 'bf16'
+    else:
+        dtype = torch.float16
+        model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.BASE, AdaptiveScalingNeckHeadType.UPERNEXT),
+                                compute_dtype=dtype).to(device).eval()
+        B = 1
+        shapes = config5_shape_sequence(args.steps + args.warmup, 4242 + rank)
+        pages = {hw: torch.randint(0, 256, (1, 3, *hw), generator=g).float().to(device) for hw in sorted(set(shapes))}
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+
+        def step(i):
+            H, W = shapes[i]
+            x = pages[(H, W)]
+            mask, height = model.forward_rough(x)
+            prob, offset, angle, dist_ = model.forward_precise(x)
+            h2, w2 = H // 2, W // 2
+            vh = torch.full((1,), h2, dtype=torch.int32, device=device)
+            vw = torch.full((1,), w2, dtype=torch.int32, device=device)
+            om = torch.empty((1, h2, w2), dtype=torch.uint8, device=device)
+            oh = torch.empty((1, h2, w2), dtype=torch.float32, device=device)
+            check(lib.vkas_rough_postprocess(ptr(mask), ptr(height), 1, h2, w2, ptr(vh), ptr(vw), 0.5, 3.0, ptr(om), ptr(oh),
+                                             ops._stream()), 'rough_postprocess')
+            op = torch.empty((1, h2, w2), dtype=torch.float32, device=device)
+            oo = torch.empty((1, h2, w2, 2), dtype=torch.float32, device=device)
+            oa = torch.empty((1, h2, w2, 4), dtype=torch.float32, device=device)
+            od = torch.empty((1, h2, w2, 4), dtype=torch.float32, device=device)
+            check(lib.vkas_precise_postprocess(ptr(prob), ptr(offset), ptr(angle), ptr(dist_), 1, h2, w2, ptr(vh), ptr(vw),
+                                               ptr(op), ptr(oo), ptr(oa), ptr(od), ops._stream()), 'precise_postprocess')
+            return om, oh, op, oo, oa, od
+        workload = ('ConvNeXt-Base + UPerNext inference (forward_rough + forward_precise + device post-processing), fp16, '
+                    'B = 1 per GPU, seeded sequence of page shapes with long edge 1536..2048 (BASELINE.json configs[4])')
+        dt_name = 'f16'
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(i)
+        sync()
+        ops.TIMER = ops.LaunchTimer()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, args.warmup + args.steps):
+            out = step(i)
+        enqueue = time.perf_counter() - t0
+        sync()
+        elapsed = time.perf_counter() - t0
+    timer, ops.TIMER = ops.TIMER, None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    for o in (out if isinstance(out, (list, tuple)) else [out]):
+        if o.is_floating_point() and not bool(torch.isfinite(o.float()).all()):
+            raise SystemExit('non-finite output in the timed region')
+    if rank != 0:
+        return
+    print(f'[bench] config {args.config}: {args.steps} steps in {elapsed:.3f} s on {world} GPU(s); host enqueue '
+          f'{enqueue:.3f} s', file=sys.stderr, flush=True)
+    images = B * world
+    timed_shapes = shapes[args.warmup:]
+    out = {'metric': 'images/sec forward (%s)' % ('backbone, no grad' if args.config == 2 else 'both inference passes'),
+           'value': round(images * args.steps / elapsed, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+           'warmup': args.warmup, 'ms_per_step': round(1000.0 * elapsed / args.steps, 3), 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': dt_name, 'data': 'synthetic',
+           'config': {'workload': workload, 'global_batch': images, 'images_per_step': images,
+                      'parallelism': f'dp{world} (independent replicas)',
+                      'collective': {'backend': dist.get_backend() if world > 1 else None, 'world_size': world},
+                      'shapes': sorted(set(timed_shapes)) if args.config == 5 else [(640, 640)],
+                      'megapixels_per_step': round(sum(h * w for h, w in timed_shapes) / len(timed_shapes) / 1e6 * B, 3),
+                      'host_enqueue_ms_per_step': round(1000.0 * enqueue / args.steps, 2)},
+           'roofline': roofline_from_timer(timer, elapsed, args.steps)}
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline_forward(args.config)
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_forward(config):
+    """The oracle's forward on the host cores for the forward-only configurations, on a bounded sample."""
+    import torch
+    from oracle import torch_oracle as O
+    from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
+                                                           AdaptiveScalingNeckHeadType, ConvNext)
+    torch.manual_seed(7)
+    torch.set_num_threads(usable_cores())
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        if config == 2:
+            sd = {k: v.detach() for k, v in ConvNext.create_tiny().state_dict().items()}
+            x = torch.randint(0, 256, (1, 3, 640, 640), generator=g).float()
+            t0 = time.perf_counter()
+            O.convnext_forward(sd, x)
+            dt = time.perf_counter() - t0
+            return {'value': 1.0 / dt, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                    'sample': f'oracle ConvNeXt-Tiny backbone forward, 1 image 640x640, fp32: {dt:.1f} s'}
+        model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.BASE, AdaptiveScalingNeckHeadType.UPERNEXT))
+        sd = {k: v.detach() for k, v in model.state_dict().items()}
+        x = torch.randint(0, 256, (1, 3, 1024, 768), generator=g).float()
+        t0 = time.perf_counter()
+        O.forward_rough(sd, x, 'upernext')
+        O.forward_precise(sd, x, 'upernext')
+        dt = time.perf_counter() - t0
+        mp_full = sum(h * w for h, w in CONFIG5_SHAPES) / len(CONFIG5_SHAPES) / 1e6
+        scaled = dt * mp_full / (1024 * 768 / 1e6)
+        return {'value': 1.0 / scaled, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                'sample': f'oracle ConvNeXt-Base+UPerNext forward_rough + forward_precise on ONE 1024x768 page, fp32: {dt:.1f} s; '
+                          f'scaled by pixel count to the mean page of the shape set ({mp_full:.2f} MP): {scaled:.1f} s/image'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -104,6 +300,10 @@ def main():
                     help='skip the single-pass / other-schedule / dense-backward side measurements (profiling runs: the '
                          'kernel statistics then cover warmup + timed steps only)')
     ap.add_argument('--detail', action='store_true', help='per-shape GEMM timing table on stderr')
+    ap.add_argument('--config', type=int, default=3, choices=(2, 3, 5),
+                    help='BASELINE.json configuration (1-based): 3 = the headline train step (default; 4 = the same with '
+                         '--gpus N), 2 = ConvNeXt-Tiny backbone forward 640x640 batch 4 bf16, 5 = ConvNeXt-Base fp16 '
+                         'inference over a seeded sequence of page shapes')
     ap.add_argument('--schedule', choices=('merged', 'two-pass'), default='merged',
                     help='merged: one backbone pass over the rough + precise batches and one backward of the summed loss '
                          '(same gradients); two-pass: the reference order, rough fwd/bwd then precise fwd/bwd')
@@ -133,6 +333,12 @@ def main():
     device = torch.device('cuda', dev_index)
     if world > 1:
         dist.init_process_group(backend, rank=rank, world_size=world)
+
+    if args.config != 3:
+        run_forward_config(args, world, rank, device, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     torch.manual_seed(1234)  # identical initial weights on every rank
@@ -239,51 +445,8 @@ def main():
                       f'{nb_ / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0:6.2f} {roof_ / args.steps:8.3f}', file=sys.stderr)
             print(f'[bench] all GEMMs: {tot_ms / args.steps:.2f} ms/step, roofline {tot_roof / args.steps:.2f} ms/step',
                   file=sys.stderr)
-        # dominant kernel = the instantiation with the largest share of the timed region.  Its roof is whichever of the
-        # two bounds is tighter for the launches it ran: algorithmic flops / dense bf16 MFMA peak or algorithmic bytes /
-        # HBM peak (the short-K layer GEMMs are HBM-bound, the 3x3 head convolutions MFMA-bound).
-        dom = max(summ, key=lambda k: summ[k]['ms']) if summ else 'none'
-
-        def stats(k):
-            fl = sum(r[3] for r in timer.records if r[0] == k)
-            nb = sum(r[7] for r in timer.records if r[0] == k)
-            ms_ = summ[k]['ms']
-            t_mfma, t_hbm = fl / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12), nb / (HBM_PEAK_GBS * 1e9)
-            bound = 'mfma' if t_mfma >= t_hbm else 'hbm'
-            ach = fl / (ms_ * 1e-3) / 1e12 if bound == 'mfma' else nb / (ms_ * 1e-3) / 1e9
-            peak = MFMA_BF16_DENSE_PEAK_TFLOPS if bound == 'mfma' else HBM_PEAK_GBS
-            return {'bound': bound, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
-                    'frac': round(ach / peak, 4), 'launches_per_step': summ[k]['launches'] / max(args.steps, 1),
-                    'avg_launch_ms': round(ms_ / max(summ[k]['launches'], 1), 4),
-                    'algorithmic_flops_per_launch': fl / max(summ[k]['launches'], 1),
-                    'algorithmic_bytes_per_launch': nb / max(summ[k]['launches'], 1),
-                    'share_of_step_time': round(ms_ / (1000.0 * elapsed), 3)}
-
-        traffic, traffic_source = None, None
-        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         default_cfg = (args.size == 1024 and args.batch == 8 and args.dtype == 'bf16')
-        if default_cfg and os.path.exists(pmc_path):  # per-launch HBM bytes from the rocprofv3 --pmc passes of this command
-            pmc_all = json.load(open(pmc_path))
-            pmc = pmc_all.get(dom)
-            if pmc:  # measured by a separate rocprofv3 run of this command, not in this run: say which one
-                traffic = pmc['bytes_per_launch']
-                traffic_source = pmc_all.get('_meta', {}).get('source', 'profiles/pmc_traffic.json')
-        is_gemm = lambda k: k.startswith(('gemm_', 'conv3x3_', 'mlp_chain_'))  # the depthwise / resize launches are timed too (HBM roofs)
-        all_gemm_flops = sum(v['flops'] for k, v in summ.items() if is_gemm(k))
-        all_gemm_ms = sum(v['ms'] for k, v in summ.items() if is_gemm(k))
-        if summ:
-            roof = stats(dom)
-            roof = {'bound': roof['bound'], 'kernel': dom, 'achieved': roof['achieved'], 'peak': roof['peak'],
-                    'unit': roof['unit'], 'frac': roof['frac'], 'traffic': traffic, 'traffic_source': traffic_source,
-                    **{k: v for k, v in roof.items() if k not in ('bound', 'achieved', 'peak', 'unit', 'frac')},
-                    'all_gemm_kernels': {'tflops': round(all_gemm_flops / (all_gemm_ms * 1e-3) / 1e12, 2) if all_gemm_ms > 0 else 0.0,
-                                         'share_of_step_time': round(all_gemm_ms / (1000.0 * elapsed), 3)},
-                    'other_kernels': {k: {kk: vv for kk, vv in stats(k).items()
-                                          if kk in ('bound', 'achieved', 'unit', 'frac', 'avg_launch_ms', 'share_of_step_time')}
-                                      for k in summ if k != dom}}
-        else:
-            roof = {'bound': 'mfma', 'kernel': 'none', 'achieved': 0.0, 'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': 0.0, 'traffic': None}
+        roof = roofline_from_timer(timer, elapsed, args.steps, use_pmc=default_cfg)
         out = {'metric': 'images/sec fwd+bwd @1024x1024 bf16 (train step: rough+precise passes, losses, backward, '
                          'clip, AdamW)', 'value': round(images / (elapsed / args.steps), 3), 'unit': 'images/s',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
@@ -293,8 +456,11 @@ def main():
                                                            f'(BASELINE.json configs[2]{"/[3]" if world > 1 else ""})',
                                                'global_batch': args.batch * world, 'images_per_step': images,
                                                'parallelism': f'dp{world}', 'pass_schedule': args.schedule,
+                                               'collective': ({'backend': dist.get_backend(), 'world_size': dist.get_world_size()}
+                                                              if world > 1 else {'backend': None, 'world_size': 1}),
                                                'label_point_backward': 'compact (B*P rows)' if ops._POINT_SPARSE else 'dense',
                                                'per_pass': per_pass,
+                                               'host_enqueue_ms_per_step': round(1000.0 * enqueue / args.steps, 2),
                                                'losses': [round(rl, 5), round(pl, 5)]},
                'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:

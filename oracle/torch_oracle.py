@@ -30,6 +30,67 @@ SD = Dict[str, Tensor]
 
 
 # ----------------------------------------------------------------------------------------
+# storage-rounding mode (a model of the 16-bit storage FORMAT, not of the reference)
+# ----------------------------------------------------------------------------------------
+# The reference computes in fp32.  The HIP path keeps activations (and the matrix operands made from weights) in
+# bf16 / fp16 between kernels and accumulates in fp32.  ``storage_rounding(dtype)`` makes this oracle round at the
+# same places - every value an op hands to the next op, forward and backward - while all arithmetic stays in the
+# tensors' own precision (fp64 in the tests).  Its distance from the plain oracle is the error the storage format
+# alone causes; tests bound the kernels' error against it (tests/test_gpu_model.py::test_bf16_flat_gradient_*).
+_STORAGE = [None]
+
+
+class _RoundBoth(torch.autograd.Function):
+    """Round an activation to the storage type; the gradient that flows back through the same edge is stored in that
+    type too."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype = dtype
+        return x.to(dtype).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
+class _RoundFwd(torch.autograd.Function):
+    """Round a weight to the storage type of the matrix operand; its gradient is accumulated in fp32 (not rounded)."""
+
+    @staticmethod
+    def forward(ctx, w, dtype):
+        return w.to(dtype).to(w.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class storage_rounding:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.old = _STORAGE[0]
+        _STORAGE[0] = self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        _STORAGE[0] = self.old
+        return False
+
+
+def _q(x: Tensor) -> Tensor:
+    """Activation storage point (no-op unless inside storage_rounding)."""
+    return x if _STORAGE[0] is None else _RoundBoth.apply(x, _STORAGE[0])
+
+
+def _qw(w: Tensor) -> Tensor:
+    """Weight operand of a matrix product / depthwise convolution."""
+    return w if _STORAGE[0] is None else _RoundFwd.apply(w, _STORAGE[0])
+
+
+# ----------------------------------------------------------------------------------------
 # primitive ops (model/helper.py)
 # ----------------------------------------------------------------------------------------
 def layer_norm_nchw(x: Tensor, g: Tensor, b: Tensor, eps: float = 1e-6) -> Tensor:
@@ -54,7 +115,7 @@ def softplus(x: Tensor) -> Tensor:
 
 def linear_nchw(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
     """helper.conv1x1 = nn.Linear on the NHWC view (model/helper.py:18-22)."""
-    y = torch.einsum('bchw,oc->bohw', x, w)
+    y = torch.einsum('bchw,oc->bohw', x, _qw(w))
     if b is not None:
         y = y + b.view(1, -1, 1, 1)
     return y
@@ -122,15 +183,15 @@ def convnext_layer(sd: SD, p: str, x: Tensor, drop_mask: Optional[Tensor]) -> Te
     Linear(4C,C) -> * block_scale -> stochastic-depth mask -> + x.  ``drop_mask`` is the already
     divided (B,1,1,1) keep mask of apply_stochastic_depth (:41-53) or None."""
     c = x.shape[1]
-    y = F.conv2d(x, sd[p + 'block.0.weight'], sd[p + 'block.0.bias'], padding=3, groups=c)
-    y = layer_norm_nchw(y, sd[p + 'block.2.weight'], sd[p + 'block.2.bias'])
-    y = linear_nchw(y, sd[p + 'block.3.weight'], sd[p + 'block.3.bias'])
-    y = gelu(y)
-    y = linear_nchw(y, sd[p + 'block.5.weight'], sd[p + 'block.5.bias'])
+    y = _q(F.conv2d(x, _qw(sd[p + 'block.0.weight']), sd[p + 'block.0.bias'], padding=3, groups=c))
+    y = _q(layer_norm_nchw(y, sd[p + 'block.2.weight'], sd[p + 'block.2.bias']))
+    y = _q(linear_nchw(y, sd[p + 'block.3.weight'], sd[p + 'block.3.bias']))
+    y = _q(gelu(y))
+    y = _q(linear_nchw(y, sd[p + 'block.5.weight'], sd[p + 'block.5.bias']))
     y = sd[p + 'block_scale'].view(1, -1, 1, 1) * y
     if drop_mask is not None:
         y = drop_mask * y
-    return y + x
+    return _q(y + x)
 
 
 def convnext_forward(sd: SD, x: Tensor, prefix: str = '',
@@ -138,8 +199,8 @@ def convnext_forward(sd: SD, x: Tensor, prefix: str = '',
     """ConvNext.forward (model/convnext.py:227-235) incl. stem (:106-123) and ConvNextBlock (:93-101)."""
     wstem = sd[prefix + 'stem.0.weight']
     k = wstem.shape[-1]
-    x = F.conv2d(x, wstem, sd[prefix + 'stem.0.bias'], stride=k)
-    x = layer_norm_nchw(x, sd[prefix + 'stem.2.weight'], sd[prefix + 'stem.2.bias'])
+    x = _q(F.conv2d(x, _qw(wstem), sd[prefix + 'stem.0.bias'], stride=k))
+    x = _q(layer_norm_nchw(x, sd[prefix + 'stem.2.weight'], sd[prefix + 'stem.2.bias']))
     feats = []
     n_blocks = _count(sd, prefix, 'blocks.{}.')
     li = 0
@@ -149,10 +210,10 @@ def convnext_forward(sd: SD, x: Tensor, prefix: str = '',
             m = None if drop_masks is None else drop_masks[li]
             x = convnext_layer(sd, f'{bp}layers.{l}.', x, m)
             li += 1
-        x = layer_norm_nchw(x, sd[bp + 'ln.1.weight'], sd[bp + 'ln.1.bias'])
+        x = _q(layer_norm_nchw(x, sd[bp + 'ln.1.weight'], sd[bp + 'ln.1.bias']))
         feats.append(x)
         if bp + 'pconv2x2.weight' in sd:
-            x = F.conv2d(x, sd[bp + 'pconv2x2.weight'], sd[bp + 'pconv2x2.bias'], stride=2)
+            x = _q(F.conv2d(x, _qw(sd[bp + 'pconv2x2.weight']), sd[bp + 'pconv2x2.bias'], stride=2))
     return feats
 
 
@@ -167,17 +228,17 @@ def stochastic_depth_probs(num_layers: Sequence[int]) -> List[float]:
 # ----------------------------------------------------------------------------------------
 def conv1x1_block(sd: SD, p: str, x: Tensor) -> Tensor:
     """build_conv1x1_block (model/upernext.py:21-36, model/fpn.py:21-28): Linear -> LN -> GELU."""
-    y = linear_nchw(x, sd[p + '1.weight'], sd[p + '1.bias'])
+    y = _q(linear_nchw(x, sd[p + '1.weight'], sd[p + '1.bias']))
     y = layer_norm_nchw(y, sd[p + '2.weight'], sd[p + '2.bias'])
-    return gelu(y)
+    return _q(gelu(y))
 
 
 def convkxk_block(sd: SD, p: str, x: Tensor) -> Tensor:
     """build_conv3x3_block / build_conv5x5_block (model/upernext.py:39-45, model/fpn.py:31-48)."""
     w = sd[p + '0.weight']
-    y = F.conv2d(x, w, sd[p + '0.bias'], padding=w.shape[-1] // 2)
+    y = _q(F.conv2d(x, _qw(w), sd[p + '0.bias'], padding=w.shape[-1] // 2))
     y = layer_norm_nchw(y, sd[p + '2.weight'], sd[p + '2.bias'])
-    return gelu(y)
+    return _q(gelu(y))
 
 
 def ppm_forward(sd: SD, p: str, x: Tensor, ppm_scales: Sequence[int]) -> Tensor:
@@ -185,9 +246,9 @@ def ppm_forward(sd: SD, p: str, x: Tensor, ppm_scales: Sequence[int]) -> Tensor:
     size = (x.shape[-2], x.shape[-1])
     feats = [x]
     for i, s in enumerate(ppm_scales):
-        f = adaptive_avg_pool(x, s)
+        f = _q(adaptive_avg_pool(x, s))
         f = conv1x1_block(sd, f'{p}ap_conv_blocks.{i}.1.', f)
-        feats.append(resize_bilinear(f, size))
+        feats.append(_q(resize_bilinear(f, size)))
     return convkxk_block(sd, p + 'final_conv_block.', torch.cat(feats, dim=1))
 
 
@@ -198,19 +259,19 @@ def upernext_neck_forward(sd: SD, feats: Sequence[Tensor], prefix: str = '',
     outs = [conv1x1_block(sd, f'{prefix}step1_conv_blocks.{i}.', feats[i]) for i in range(n - 1)]
     outs.append(ppm_forward(sd, f'{prefix}step1_conv_blocks.{n - 1}.', feats[n - 1], ppm_scales))
     for i in range(n - 1, 0, -1):
-        outs[i - 1] = outs[i - 1] + resize_bilinear(outs[i], outs[i - 1].shape[-2:])
+        outs[i - 1] = _q(outs[i - 1] + resize_bilinear(outs[i], outs[i - 1].shape[-2:]))
     for i in range(n - 1):
         outs[i] = convkxk_block(sd, f'{prefix}step2_conv_blocks.{i}.', outs[i])
     size0 = feats[0].shape[-2:]
     for i in range(1, n):
-        outs[i] = resize_bilinear(outs[i], size0)
+        outs[i] = _q(resize_bilinear(outs[i], size0))
     return torch.cat(outs, dim=1)
 
 
 def upernext_head_forward(sd: SD, x: Tensor, prefix: str, upsampling_factor: int) -> Tensor:
     """UperNextHead.forward (model/upernext.py:233-248)."""
     if upsampling_factor > 1:
-        x = resize_bilinear(x, (x.shape[-2] * upsampling_factor, x.shape[-1] * upsampling_factor))
+        x = _q(resize_bilinear(x, (x.shape[-2] * upsampling_factor, x.shape[-1] * upsampling_factor)))
     x = convkxk_block(sd, prefix + 'step1_conv3x3.', x)
     return linear_nchw(x, sd[prefix + 'step2_conv1x1.1.weight'], sd[prefix + 'step2_conv1x1.1.bias'])
 
@@ -220,7 +281,7 @@ def fpn_neck_forward(sd: SD, feats: Sequence[Tensor], prefix: str = '') -> Tenso
     n = len(feats)
     outs = [conv1x1_block(sd, f'{prefix}step1_conv_blocks.{i}.', feats[i]) for i in range(n)]
     for i in range(n - 1, 0, -1):
-        outs[i - 1] = outs[i - 1] + resize_nearest(outs[i], outs[i - 1].shape[-2:])
+        outs[i - 1] = _q(outs[i - 1] + resize_nearest(outs[i], outs[i - 1].shape[-2:]))
     for i in range(n):
         outs[i] = convkxk_block(sd, f'{prefix}step2_conv_blocks.{i}.', outs[i])
     size0 = feats[0].shape[-2:]

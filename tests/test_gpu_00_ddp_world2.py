@@ -1,0 +1,119 @@
+"""The N > 1 path of the REAL model on the device: two fresh child processes (ranks), both on GPU 0, ``gloo`` collectives.
+
+AdaptiveScaling (ConvNeXt-T + UPerNext, the HIP ops with their direct gradient delivery into the flat buffer) +
+FlatBuffers + BucketedGradReducer + TwoPassStep, for both pass schedules:
+  * construction broadcasts rank 0's parameters (the ranks are seeded differently on purpose);
+  * every bucket's all-reduce is launched by the LAST gradient delivery of the bucket, in the designed order
+    (two-pass: rough after backward #1, then precise, backbone3..0 during backward #2; merged: rough/precise, then
+    backbone3..0), and none is left for flush() to launch - i.e. every parameter delivers exactly once per armed backward;
+  * the reduced flat gradient equals the mean over ranks of the gradients each rank computes alone (no reducer) on its own
+    batch.
+RCCL itself needs N GPUs and is exercised by the driver's scaling run; this covers everything around the collective call
+(SURVEY.md §8(e)).  The file name sorts first among the -m gpu files: the parent has not touched the GPU when it starts
+the children (the test only counts devices, which does not initialise HIP on this image)."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import bench
+        from vkit_ocr_model_adaptive_scaling_amd import ops
+        from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
+                                                               AdaptiveScalingNeckHeadType)
+        from vkit_ocr_model_adaptive_scaling_amd.loss_function import (
+            AdaptiveScalingRoughLossFunction, AdaptiveScalingRoughLossFunctionConifg,
+            AdaptiveScalingPreciseLossFunction, AdaptiveScalingPreciseLossFunctionConifg)
+        from vkit_ocr_model_adaptive_scaling_amd.training import (FlatBuffers, BucketedGradReducer, TwoPassStep,
+                                                                  adaptive_scaling_buckets)
+        dev = torch.device('cuda', 0)
+        torch.manual_seed(1000 + rank)  # different initial weights per rank: the reducer must broadcast rank 0's
+        model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.TINY, AdaptiveScalingNeckHeadType.UPERNEXT),
+                                compute_dtype=torch.bfloat16).to(dev).eval()  # eval: no random stochastic-depth masks
+        with torch.no_grad():  # layer scale O(1) so that every branch carries gradient
+            for n, p in model.named_parameters():
+                if n.endswith('block_scale'):
+                    p.fill_(0.5)
+        flat = FlatBuffers(model.named_parameters())
+        red = BucketedGradReducer(flat, adaptive_scaling_buckets(model))
+        assert red.world_size == world
+        sums = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(sums, torch.stack([flat.flat_param.double().sum(), flat.flat_param.double().abs().sum()]))
+        assert all(torch.equal(sums[0], s) for s in sums), 'parameters differ across ranks after construction'
+        rough, precise = bench.synthetic_batches(1, (256, 256), dev, 500 + rank)  # each rank its own batch
+        rl = AdaptiveScalingRoughLossFunction(AdaptiveScalingRoughLossFunctionConifg())
+        pl = AdaptiveScalingPreciseLossFunction(AdaptiveScalingPreciseLossFunctionConifg())
+
+        class KeepGrads:  # TwoPassStep's optimizer slot: leave the (reduced) gradient in the flat buffer
+            def step(self, lr=None):
+                pass
+
+            def zero_grad(self):
+                pass
+
+        # what this rank computes alone (world-1 code path, no reducer), then the mean over ranks
+        flat.zero_grad()
+        TwoPassStep(model, rl, pl, KeepGrads())(rough, precise)
+        torch.cuda.synchronize()
+        alone = flat.flat_grad.clone()
+        assert float(alone.norm()) > 0 and bool(torch.isfinite(alone).all())
+        mean = alone.clone()
+        dist.all_reduce(mean)
+        mean /= world
+        names = [b for b, _ in adaptive_scaling_buckets(model)]
+        backbone = [b for b in names if b.startswith('backbone')]
+        assert backbone == ['backbone3', 'backbone2', 'backbone1', 'backbone0']
+        left_armed = []
+        real_flush = red.flush
+
+        def flush(bucket_names=()):
+            left_armed.extend(b.name for b in red.buckets.values() if b.armed)
+            return real_flush(bucket_names)
+        red.flush = flush
+        for merged in (False, True):
+            flat.zero_grad()
+            red.launch_log.clear()
+            left_armed.clear()
+            TwoPassStep(model, rl, pl, KeepGrads(), red, merge_backbone=merged)(rough, precise)
+            torch.cuda.synchronize()
+            assert not left_armed, (merged, left_armed)           # every bucket fired from its last delivery
+            assert not red._works
+            if merged:
+                assert sorted(red.launch_log[:2]) == ['precise', 'rough'] and red.launch_log[2:] == backbone, red.launch_log
+            else:
+                assert red.launch_log == ['rough', 'precise'] + backbone, red.launch_log
+            err = float((flat.flat_grad.double() - mean.double()).norm() / mean.double().norm())
+            # same kernels on the same data; what differs is the order of fp32 atomics and of the two-term sums
+            assert err < 1e-4, (merged, err)
+            both = [torch.zeros_like(flat.flat_grad) for _ in range(world)]
+            dist.all_gather(both, flat.flat_grad)
+            assert torch.equal(both[0], both[1]), 'ranks hold different reduced gradients'
+            if rank == 0:
+                open(os.path.join(out_dir, 'merged' if merged else 'two_pass'), 'w').write('%.3e' % err)
+        ops.check_deferred(wait=True)
+        assert all(flat.touched), 'a trainable parameter never received a gradient'
+    finally:
+        dist.destroy_process_group()
+
+
+def test_real_model_reducer_world2_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    assert torch.cuda.device_count() >= 1
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    from tests import parity_log
+    for name in ('two_pass', 'merged'):
+        err = float(open(str(tmp_path / name)).read())
+        parity_log.record('ddp_world2_gloo[%s]' % name, 'reduced flat gradient vs mean of per-rank gradients', err, 1e-4)

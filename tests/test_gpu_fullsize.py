@@ -187,6 +187,13 @@ def test_train_step_matches_oracle_and_torch_adamw(dtype):
     opt = FlatAdamW(None, lr=8e-4, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=2.5, flat=flat)
     step = TwoPassStep(model, AdaptiveScalingRoughLossFunction(AdaptiveScalingRoughLossFunctionConifg()),
                        AdaptiveScalingPreciseLossFunction(AdaptiveScalingPreciseLossFunctionConifg()), opt)
+    seen = {}
+    opt_step = opt.step
+
+    def capturing_step(lr=None):
+        seen['grad'] = flat.flat_grad.detach().clone()   # accumulated, un-clipped gradient of both passes
+        opt_step(lr=lr)
+    opt.step = capturing_step
     rl, pl = step(rough, precise, lr=8e-4)
     # host reference
     ref = {k: torch.nn.Parameter(v.clone()) for k, v in sd0.items()}
@@ -204,6 +211,29 @@ def test_train_step_matches_oracle_and_torch_adamw(dtype):
     lp_.backward()
     tol_l = 1e-4 if dtype == torch.float32 else 1e-2
     assert abs(float(rl) - float(lr_)) <= tol_l * abs(float(lr_)) and abs(float(pl) - float(lp_)) <= tol_l * abs(float(lp_))
+    from tests import parity_log
+    tag = 'train_step_128[%s]' % ('f32' if dtype == torch.float32 else 'bf16')
+    g_dev = seen['grad'].double().cpu()
+    g_got = torch.cat([g_dev[s0:s0 + n] for s0, n in (flat.offsets[k] for k in flat.names)])
+    g_ref = torch.cat([ref[k].grad.reshape(-1) for k in flat.names])
+    ge = rel(g_got, g_ref)
+    gtol = 1e-3 if dtype == torch.float32 else 1e-2   # north_star: gradient within 1e-2 in bf16
+    if dtype != torch.float32:
+        # what bf16 storage alone does to this gradient (oracle with rounded stored activations, no kernels)
+        refq = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+        with O.storage_rounding(dtype):
+            mq, hq = O.forward_rough(refq, r['image'], 'upernext')
+            (O.rough_loss(mq, hq, r['downsampled_mask'], r['downsampled_score_map'], cb) / 2).backward()
+            oq = O.forward_precise(refq, p['image'], 'upernext')
+            (O.precise_loss(*oq, p['downsampled_score_map'], p['downsampled_mask'], cb, p['downsampled_label_point_y'],
+                            p['downsampled_label_point_x'], p['up_left_offsets'], p['corner_angles'],
+                            p['corner_distances']) / 2).backward()
+        qe = rel(torch.cat([refq[k].grad.reshape(-1) for k in flat.names]), g_ref)
+        gtol = max(gtol, 1.1 * qe)
+        parity_log.record(tag, 'storage-rounded oracle vs oracle: flat gradient', qe, None, 'format error, no kernels')
+    parity_log.record(tag, 'flat gradient before the clip', ge, gtol)
+    print('train-step gradient rel err', dtype, ge)
+    assert ge < gtol, ge
     params = list(ref.values())
     torch.nn.utils.clip_grad_norm_(params, 2.5)
     torch.optim.AdamW(params, lr=8e-4, betas=(0.9, 0.999), weight_decay=0.01).step()
@@ -211,8 +241,13 @@ def test_train_step_matches_oracle_and_torch_adamw(dtype):
     upd = torch.cat([(v.detach().cpu().double() - sd0[k]).reshape(-1) for k, v in model.state_dict().items()])
     e = rel(upd, upd_ref)
     print('train-step update rel err', dtype, e)
-    # Adam's first step is sign-like (m / sqrt(v) = +-1), so tiny gradient differences flip few entries: compare norm-wise
-    assert e < (2e-3 if dtype == torch.float32 else 1.5e-1)
+    # The gradient is what is held to the north-star bound (above).  Adam's FIRST update is lr * sign(g) wherever |g| >> eps
+    # (m / sqrt(v) = +-1): an entry whose gradient is near zero flips sign on a 1e-2 perturbation and then contributes
+    # 2 lr, so this is a coarse check of clip + AdamW + weight decay on top of that gradient, not a numerics bound:
+    # fraction of flipped entries ~ e^2 / 4
+    utol = 2e-3 if dtype == torch.float32 else 1.5e-1
+    parity_log.record(tag, 'first AdamW update (sign-like, see the test)', e, utol)
+    assert e < utol
     assert float(flat.flat_grad.abs().max()) == 0.0  # zero_grad() ran
 
 

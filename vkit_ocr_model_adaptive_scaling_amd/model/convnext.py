@@ -158,7 +158,8 @@ class ConvNext(nn.Module):
         pconv, norm = self.stem[0], self.stem[2]
         k = pconv.kernel_size[0]
         a = ops.ImageToAct.apply(x, self.compute_dtype)
-        a = ops.Conv.apply(a, pconv.weight, pconv.bias, k, 0, False)
+        # the gradient w.r.t. the image exists only when the caller asks for it (x.requires_grad): training feeds data
+        a = ops.Conv.apply(a, pconv.weight, pconv.bias, k, 0, bool(x.requires_grad and torch.is_grad_enabled()))
         a = ops.LayerNorm.apply(a, norm.weight, norm.bias, False)
         feats = []
         li = 0

@@ -530,8 +530,10 @@ def copy_channels(x, out, accumulate=False):
 
 # ---------------------------------------------------------------------------------------- autograd ops
 class ImageToAct(Function):
-    """(B,3,H,W) fp32 NCHW raw pixels -> (B,H,W,8) activation (channels 3..7 zero).  No gradient: the model
-    input is data (train.py:399-403)."""
+    """(B,3,H,W) fp32 NCHW raw pixels -> (B,H,W,8) activation (channels 3..7 zero).  The reference's stem is a plain
+    nn.Conv2d (convnext.py:106-123), so an input that requires grad receives one: backward converts the stem
+    convolution's NHWC input gradient back to (B,3,H,W) fp32.  Training feeds data (train.py:399-403): no gradient is
+    computed then (the caller passes need_input_grad=False to the stem convolution as well)."""
 
     @staticmethod
     def forward(ctx, img: torch.Tensor, dtype: torch.dtype):
@@ -544,12 +546,18 @@ class ImageToAct(Function):
         check(lib.vkas_image_nchw_to_nhwc8(_p(img), _p(out), B, C, H, W,
                                            _dtc(dtype), _stream()),
               'image_nchw_to_nhwc8')
-        ctx.mark_non_differentiable(out)
+        ctx.C = C
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return None, None
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        g = as_act(g)
+        B, H, W, Cp = g.shape
+        out = torch.empty((B, ctx.C, H, W), dtype=_FLOAT, device=g.device)
+        check(lib.vkas_nhwc_to_nchw_f32(_p(g), act_ld(g), _p(out), B, H, W, ctx.C, _dt(g), _stream()), 'nhwc_to_nchw_f32')
+        return out, None
 
 
 class Conv(Function):
@@ -1071,25 +1079,35 @@ _POINT_SPARSE = os.environ.get('VKAS_POINT_SPARSE_BWD', '1') != '0'
 
 def point_sparse(grad: torch.Tensor, py: torch.Tensor, px: torch.Tensor) -> torch.Tensor:
     """Mark ``grad`` - a dense (B, C, H, W) or (B, H, W, C) gradient - as zero everywhere but at the label points (py, px)
-    of its images.  The mark is a Python attribute of this very tensor object: autograd hands the same object to the next
-    backward function when the gradient has a single consumer, and anything that builds a new tensor (a sum with another
-    gradient, a view, a cast) drops the mark, so a consumer that finds it can rely on it.  Only functions that keep the
-    zero pattern (per-pixel maps) may pass it on (``pass_point_sparse``)."""
-    grad._vkas_points = (py, px)
+    of its images.  The mark is a Python attribute of this very tensor object, stamped with the tensor's version counter:
+    autograd hands the same object to the next backward function when the gradient has a single consumer; anything that
+    builds a new tensor (an out-of-place sum with another consumer's gradient, a view, a cast) drops the attribute, and
+    anything that writes into this tensor - autograd's input buffer accumulates IN PLACE (``old += new``) when it holds the
+    last reference, a tensor hook may call ``g.add_()`` - bumps the version, which voids the mark (``point_mark``).  Only
+    functions that keep the zero pattern (per-pixel maps) may pass it on (``pass_point_sparse``)."""
+    grad._vkas_points = (py, px, grad._version)
     return grad
 
 
+def point_mark(t: Optional[torch.Tensor]):
+    """(py, px) if ``t`` carries a label-point mark that is still valid (nothing wrote into t since it was marked)."""
+    m = getattr(t, '_vkas_points', None) if t is not None else None
+    if m is None or t._version != m[2]:
+        return None
+    return m[0], m[1]
+
+
 def pass_point_sparse(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
-    pts = getattr(src, '_vkas_points', None)
+    pts = point_mark(src)
     if pts is not None:
-        dst._vkas_points = pts
+        point_sparse(dst, pts[0], pts[1])
     return dst
 
 
 def _point_sparse_run(dprojs, B, H, W):
     """(h0, h1, py, px) when the heads [h0, h1) - a prefix or a suffix of the heads, so that the others stay one contiguous
     run of z columns - all carry the mark of the SAME label points and the compact path pays (points << pixels)."""
-    marks = [getattr(d, '_vkas_points', None) if d is not None else None for d in dprojs]
+    marks = [point_mark(d) for d in dprojs]
     idx = [h for h, m in enumerate(marks) if m is not None]
     if not idx:
         return None

@@ -26,7 +26,7 @@ class Bucket:
     def __init__(self, name: str, start: int, end: int, param_names: Sequence[str]):
         self.name, self.start, self.end = name, start, end
         self.param_names = list(param_names)
-        self.pending = 0
+        self.waiting = set()   # parameters of this bucket that have not delivered their gradient in the armed backward
         self.armed = False
 
 
@@ -64,18 +64,22 @@ class BucketedGradReducer:
         b = self._param_bucket[name]
         if not b.armed:
             return
-        b.pending -= 1
-        if b.pending == 0:
+        # a delivery is reported per USE of a parameter by the ops' direct path (and once per backward by autograd's
+        # accumulation hook): count each parameter once, so that a parameter used twice in one graph cannot fire its
+        # bucket while another parameter's gradient is still missing.  (Its own later contributions would be missed by
+        # an early launch all the same: a model that re-uses a parameter must put it in a bucket that is flushed.)
+        b.waiting.discard(name)
+        if not b.waiting:
             b.armed = False
             self._launch(b)
 
-    def arm(self, bucket_names: Sequence[str], expected: Optional[Dict[str, int]] = None):
+    def arm(self, bucket_names: Sequence[str], expected: Optional[Dict[str, Sequence[str]]] = None):
         """Arm buckets for the next backward: each launches when all its parameters have accumulated a gradient.
-        ``expected`` overrides the number of parameters that will receive a gradient in this pass."""
+        ``expected`` names, per bucket, the parameters that will receive a gradient in this pass when that is a subset."""
         for bn in bucket_names:
             b = self.buckets[bn]
-            b.pending = expected[bn] if expected and bn in expected else len(b.param_names)
-            b.armed = b.pending > 0
+            b.waiting = set(expected[bn]) if expected and bn in expected else set(b.param_names)
+            b.armed = len(b.waiting) > 0
 
     def _launch(self, b: Bucket):
         self.launch_log.append(b.name)
