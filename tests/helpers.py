@@ -35,18 +35,23 @@ def rel_err(a, b) -> float:
     return d / n if n > 0 else d
 
 
-def check_grad_summary(named_grads, g, tol, prefix='', min_checked=1, skip_missing=False, atol_frac=1e-6, tag=None):
+def check_grad_summary(named_grads, g, tol, prefix='', min_checked=1, skip_missing=False, atol_frac=1e-6, tag=None,
+                       fmt_grads=None):
     """named_grads: name -> tensor with .grad (or name -> grad tensor).  Compares norm / strided samples with the stored
     reference summaries (the fixtures hold summaries, not whole gradients: the whole-vector comparison against the oracle
     is tests/test_gpu_model.py::test_flat_gradient_north_star).  Gradients whose reference norm is ~0 relative to the
     largest one are compared absolutely.  The samples of one parameter are compared as a vector (norm-wise over the 32
     strided positions), relative to the larger of the samples' norm and the gradient's rms over as many elements.
-    tag: record the worst measured errors in the parity report under this name."""
+    tag: record the worst measured errors in the parity report under this name.
+    fmt_grads (16-bit storage modes): name -> the same gradient from the ORACLE with its stored activations rounded to the
+    storage type (oracle.storage_rounding: the error of the format alone, no kernels).  A parameter may then exceed ``tol``
+    only as far as twice what the format alone does to that very statistic of that very parameter."""
     names = [k[len(prefix) + 6:] for k in g.files if k.startswith(prefix + 'gnorm/')]
     assert len(names) >= min_checked
     gmax = max(float(g[f'{prefix}gnorm/{n}']) for n in names)
     checked = 0
     worst_norm, worst_samp = (0.0, ''), (0.0, '')
+    over = 0
     for n in names:
         t = named_grads.get(n)
         if t is None:
@@ -59,18 +64,28 @@ def check_grad_summary(named_grads, g, tol, prefix='', min_checked=1, skip_missi
         samp = gr[recipe.sample_indices(gr.numel())].numpy()
         ref_samp = g[f'{prefix}gsamp/{n}']
         floor = atol_frac * gmax
-        assert abs(float(gr.norm()) - ref_norm) <= tol * ref_norm + floor, (n, float(gr.norm()), ref_norm)
+        fmt_n = fmt_s = 0.0
+        if fmt_grads is not None:
+            q = fmt_grads[n].detach().double().cpu().reshape(-1)
+            fmt_n = abs(float(q.norm()) - ref_norm)
+            fmt_s = float(np.linalg.norm(q[recipe.sample_indices(q.numel())].numpy() - ref_samp))
+        assert abs(float(gr.norm()) - ref_norm) <= max(tol * ref_norm, 2.0 * fmt_n) + floor, (n, float(gr.norm()), ref_norm, fmt_n)
         rms = ref_norm / max(1.0, np.sqrt(gr.numel()))
         denom = max(float(np.linalg.norm(ref_samp)), rms * np.sqrt(len(ref_samp)))
         serr = float(np.linalg.norm(samp - ref_samp))
-        assert serr <= tol * denom + floor * np.sqrt(len(ref_samp)), (n, serr / max(denom, 1e-300))
+        assert serr <= max(tol * denom, 2.0 * fmt_s) + floor * np.sqrt(len(ref_samp)), (
+            n, serr / max(denom, 1e-300), fmt_s / max(denom, 1e-300))
         if ref_norm > 1e-3 * gmax:
             worst_norm = max(worst_norm, (abs(float(gr.norm()) - ref_norm) / ref_norm, n))
-            worst_samp = max(worst_samp, (serr / denom, n))
+            worst_samp = max(worst_samp, (serr / denom, n + (' (format alone: %.3e)' % (fmt_s / denom) if fmt_grads is not None else '')))
+            over += int(serr > tol * denom + floor * np.sqrt(len(ref_samp)))
         checked += 1
     if tag is not None:
         from tests import parity_log
         parity_log.record(tag, prefix + 'worst |norm - ref norm| / ref norm over %d parameters' % checked, worst_norm[0], tol,
                           worst_norm[1])
         parity_log.record(tag, prefix + 'worst strided-sample error (norm-wise, 32 samples)', worst_samp[0], tol, worst_samp[1])
+        if fmt_grads is not None:
+            parity_log.record(tag, prefix + 'parameters whose samples exceed the bound (each within 2x its format error)',
+                              over, None, 'of %d' % checked)
     return checked

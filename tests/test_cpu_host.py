@@ -373,3 +373,27 @@ def test_run_training_loop_rules(tmp_path):
     assert rs.epoch_idx == 1 and set(rs.model_jit_state_dict) == {'lin.weight', 'lin.bias'}
     sd = rs.optimizer_scheduler_state_dict  # the scheduler's state after its last call of epoch 1: step(1 + 2/3)
     assert sd['last_epoch'] == 1 and abs(sd['T_cur'] - (1 + 2 / 3)) < 1e-12
+
+
+def test_torch_jit_script_owns_the_reference_schema_and_refuses_the_cpu(tmp_path):
+    """train.py:277-280 scripts the model on the host, then moves it: torch.jit.script(model) must succeed without a GPU, the
+    scripted module must carry the reference's state-dict keys (train.py:599 saves model_jit.state_dict()) on the SAME
+    tensors as the eager module, survive torch.jit.save / load, and its forward must fail loudly on a CPU tensor."""
+    from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
+                                                           AdaptiveScalingNeckHeadType, scripting)
+    model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.TINY, AdaptiveScalingNeckHeadType.UPERNEXT))
+    jit = torch.jit.script(model)
+    assert list(jit.state_dict()) == list(model.state_dict())
+    assert all(a.data_ptr() == b.data_ptr() for a, b in zip(jit.parameters(), model.parameters()))
+    assert 'vkas::adaptive_scaling_forward' in str(jit.forward_rough.graph) + str(jit.forward_precise.graph)
+    with pytest.raises(RuntimeError, match='MI355X only'):
+        jit.forward_rough(torch.zeros(1, 3, 32, 32))
+    path = str(tmp_path / 'model_jit.pt')
+    torch.jit.save(jit, path)
+    del jit, model
+    loaded = torch.jit.load(path)
+    assert len(loaded.state_dict()) == 304 and loaded._script_spec.count('upernext') == 1
+    # the operator's kernel rebuilds an eager module around the loaded tensors (no copy)
+    eager = scripting._model_for(list(loaded.parameters()), loaded._script_spec)
+    assert all(a is b for a, b in zip(eager.parameters(), loaded.parameters()))
+    assert eager.compute_dtype == torch.bfloat16

@@ -106,7 +106,12 @@ __device__ __forceinline__ void dst_range(int i, int n_in, int n_out, float scal
 
 // dx[b,iy,ix] (+)= sum over destination pixels (oy,ox) of weight(oy->iy) * weight(ox->ix) * dy[b,oy,ox]
 // grid.x = B*Hin rows, grid.y = chunks of 256 (pixel, vector) pairs of one source row.
-template <typename T>
+// R = destination columns whose x weight is evaluated ONCE per source pixel and kept in registers (a x4 / x8 upsample - the
+// necks' final resize to level-0 size, upernext.py:191-195 - has 8 / 16 of them): the index function is then evaluated
+// nx + ny times per source pixel instead of nx * ny times (at x8 that arithmetic, not the 256 L1 / L2 resident loads, was
+// 90% of the launch).  Columns beyond R (never at the instantiated factors) take the per-pair evaluation.  Same products,
+// same order (oy ascending, then ox ascending) as before: bit-identical sums.
+template <typename T, int R>
 __global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ dy, long lddy, T* __restrict__ dx,
                                                          long lddx, int Hin, int Win, int Hout, int Wout, int nvec,
                                                          int mode, int accumulate) {
@@ -123,41 +128,30 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ d
   int oy_lo, oy_hi, ox_lo, ox_hi;
   dst_range(iy, Hin, Hout, sy, mode, oy_lo, oy_hi);
   dst_range(ix, Win, Wout, sx, mode, ox_lo, ox_hi);
-  if (oy_hi - oy_lo < 4 && ox_hi - ox_lo < 4) {
-    // the common x2 case: at most 4 x 4 destinations; the axis weights are evaluated once per axis, not once per pair
-    // (the index arithmetic, not the 16 loads, was the cost of this kernel)
-    float wy4[4], wx4[4];
+  float wxr[R];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      wy4[j] = oy_lo + j <= oy_hi ? axis_weight(oy_lo + j, sy, Hin, Hout, iy, mode) : 0.f;
-      wx4[j] = ox_lo + j <= ox_hi ? axis_weight(ox_lo + j, sx, Win, Wout, ix, mode) : 0.f;
+  for (int j = 0; j < R; ++j) wxr[j] = ox_lo + j <= ox_hi ? axis_weight(ox_lo + j, sx, Win, Wout, ix, mode) : 0.f;
+  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+    const float wyv = axis_weight(oy, sy, Hin, Hout, iy, mode);
+    if (wyv == 0.f) continue;
+    const T* rowp = db + ((long)oy * Wout + ox_lo) * lddy;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      if (wxr[j] == 0.f) continue;
+      float t[8];
+      load8(rowp + (long)j * lddy, t);
+      const float wgt = wyv * wxr[j];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = fmaf(wgt, t[k], acc[k]);
     }
+    for (int ox = ox_lo + R; ox <= ox_hi; ++ox) {
+      const float wxv = axis_weight(ox, sx, Win, Wout, ix, mode);
+      if (wxv == 0.f) continue;
+      float t[8];
+      load8(db + ((long)oy * Wout + ox) * lddy, t);
+      const float wgt = wyv * wxv;
 #pragma unroll
-    for (int jy = 0; jy < 4; ++jy) {
-      if (wy4[jy] == 0.f) continue;
-#pragma unroll
-      for (int jx = 0; jx < 4; ++jx) {
-        if (wx4[jx] == 0.f) continue;
-        float t[8];
-        load8(db + ((long)(oy_lo + jy) * Wout + ox_lo + jx) * lddy, t);
-        const float wgt = wy4[jy] * wx4[jx];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = fmaf(wgt, t[k], acc[k]);
-      }
-    }
-  } else {
-    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-      const float wyv = axis_weight(oy, sy, Hin, Hout, iy, mode);
-      if (wyv == 0.f) continue;
-      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        const float wxv = axis_weight(ox, sx, Win, Wout, ix, mode);
-        if (wxv == 0.f) continue;
-        float t[8];
-        load8(db + ((long)oy * Wout + ox) * lddy, t);
-        const float wgt = wyv * wxv;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = fmaf(wgt, t[k], acc[k]);
-      }
+      for (int k = 0; k < 8; ++k) acc[k] = fmaf(wgt, t[k], acc[k]);
     }
   }
   T* dst = dx + (((long)b * Hin + iy) * Win + ix) * lddx + v * 8;
@@ -479,8 +473,13 @@ extern "C" int vkas_resize_bwd(const void* dy, long lddy, void* dx, long lddx, i
           (const T*)dy, lddy, (T*)dx, lddx, Hin, Win, Hout, Wout, Cp / 8, mode, accumulate);
     } else {
       dim3 grid((unsigned)((long)B * Hin), (unsigned)vkas_cdiv((long)Win * (Cp / 8), 256));
-      resize_bwd_kernel<T><<<grid, 256, 0, vkas_stream(stream)>>>((const T*)dy, lddy, (T*)dx, lddx, Hin, Win, Hout, Wout,
-                                                                 Cp / 8, mode, accumulate);
+      // destination columns per source pixel: at most 2 * ceil(Wout / Win) for bilinear (+ the clamped border run)
+      if (2 * vkas_cdiv(Wout, Win) <= 8)
+        resize_bwd_kernel<T, 8><<<grid, 256, 0, vkas_stream(stream)>>>((const T*)dy, lddy, (T*)dx, lddx, Hin, Win, Hout, Wout,
+                                                                      Cp / 8, mode, accumulate);
+      else
+        resize_bwd_kernel<T, 16><<<grid, 256, 0, vkas_stream(stream)>>>((const T*)dy, lddy, (T*)dx, lddx, Hin, Win, Hout,
+                                                                       Wout, Cp / 8, mode, accumulate);
     }
   })
   VKAS_LAUNCH_CHECK("resize_bwd");

@@ -1,7 +1,7 @@
 """AdaptiveScaling model assembly (mirror of vkit_open_model/model/adaptive_scaling.py) on the HIP ops."""
 import logging
 from enum import Enum, unique
-from typing import Dict, Mapping, Optional, Sequence, Tuple
+from typing import Dict, List, Mapping, Optional, Sequence, Tuple
 
 import attrs
 import os
@@ -14,6 +14,7 @@ from .convnext import ConvNext
 from .fpn import FpnNeck, FpnHead
 from .upernext import UperNextNeck, UperNextHead
 from .helper import set_compute_dtype
+from . import scripting
 from .. import ops
 
 logger = logging.getLogger(__name__)
@@ -47,6 +48,7 @@ class AdaptiveScalingConfig:
 class _SoftplusSlot(nn.Module):
     """Occupies index 1 of the Softplus-wrapped heads (adaptive_scaling.py:93-102,133-141); applied via ops.Softplus."""
 
+    @torch.jit.unused
     def forward(self, x):
         return ops.Softplus.apply(x)
 
@@ -70,6 +72,10 @@ _BACKBONES = {
 
 
 class AdaptiveScaling(nn.Module):
+    # what torch.jit.script(model) compiles forward_rough / forward_precise against (model/scripting.py): the parameter
+    # tensors in named_parameters() order and the construction recipe
+    _script_params: List[torch.Tensor]
+    _script_spec: str
 
     def __init__(self, config: AdaptiveScalingConfig, compute_dtype: torch.dtype = torch.bfloat16):
         super().__init__()
@@ -99,11 +105,20 @@ class AdaptiveScaling(nn.Module):
         self.precise_char_up_left_corner_offset_head = head(2, pf)
         self.precise_char_corner_angle_head = head(4, pf)
         self.precise_char_corner_distance_head = nn.Sequential(head(4, pf), _SoftplusSlot())
+        self.config = config
+        self.compute_dtype = compute_dtype
+        self._script_params = [p for _, p in self.named_parameters()]
+        self._script_spec = ''
         set_compute_dtype(self, compute_dtype)
+        scripting.register_live(self)
 
     def set_compute_dtype(self, dtype: torch.dtype):
         return set_compute_dtype(self, dtype)
 
+    def _refresh_script_spec(self):
+        self._script_spec = scripting.make_spec(self.config, self.compute_dtype)
+
+    @torch.jit.unused
     def _run_heads(self, neck_feature: torch.Tensor, heads: Sequence[nn.Module], label_points=None, n_dense: int = 1):
         """All heads of a pass read the same neck feature (adaptive_scaling.py:150-152,163-170): upsample it once and
         run their 3x3 convolutions as ONE implicit GEMM (output channels of the heads side by side, each padded to a
@@ -147,14 +162,40 @@ class AdaptiveScaling(nn.Module):
             outs.append(h[1](y) if isinstance(h, nn.Sequential) else y)
         return tuple(outs)
 
-    def forward_rough(self, x: torch.Tensor, drop_masks=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    @torch.jit.export
+    def forward_rough(self, x: torch.Tensor,
+                      drop_masks: Optional[List[Optional[torch.Tensor]]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """adaptive_scaling.py:143-154.  Scripted (train.py:278): one call of vkas::adaptive_scaling_forward, which runs
+        _forward_rough_eager on the same parameter tensors (model/scripting.py)."""
+        if torch.jit.is_scripting():
+            assert drop_masks is None, 'explicit stochastic-depth masks are an eager-mode extension'
+            outs = torch.ops.vkas.adaptive_scaling_forward(x, self._script_params, self._script_spec, 0, self.training)
+            return outs[0], outs[1]
+        else:
+            return self._forward_rough_eager(x, drop_masks)
+
+    @torch.jit.export
+    def forward_precise(self, x: torch.Tensor, drop_masks: Optional[List[Optional[torch.Tensor]]] = None,
+                        label_points: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+                        ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """adaptive_scaling.py:156-177; see forward_rough and _forward_precise_eager."""
+        if torch.jit.is_scripting():
+            assert drop_masks is None and label_points is None, 'eager-mode extensions'
+            outs = torch.ops.vkas.adaptive_scaling_forward(x, self._script_params, self._script_spec, 1, self.training)
+            return outs[0], outs[1], outs[2], outs[3]
+        else:
+            return self._forward_precise_eager(x, drop_masks, label_points)
+
+    @torch.jit.unused
+    def _forward_rough_eager(self, x: torch.Tensor, drop_masks=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """adaptive_scaling.py:143-154"""
         feats = self.backbone.forward_act(x, drop_masks)
         neck = self.rough_neck.forward_act(feats)
         return self._run_heads(neck, (self.rough_char_mask_head, self.rough_char_height_head))  # type: ignore
 
-    def forward_precise(self, x: torch.Tensor, drop_masks=None,
-                        label_points=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    @torch.jit.unused
+    def _forward_precise_eager(self, x: torch.Tensor, drop_masks=None,
+                               label_points=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
         """adaptive_scaling.py:156-177.  ``label_points`` = (y, x) (B,P) int64 is an extension for training steps only (see
         ops.HeadsAtPoints): the offset / angle / distance maps are then valid at those points and zero elsewhere."""
         feats = self.backbone.forward_act(x, drop_masks)
@@ -163,6 +204,7 @@ class AdaptiveScaling(nn.Module):
                                       self.precise_char_corner_angle_head,
                                       self.precise_char_corner_distance_head), label_points)  # type: ignore
 
+    @torch.jit.unused
     def forward_both(self, x_rough: torch.Tensor, x_precise: torch.Tensor, drop_masks=None, precise_label_points=None):
         """forward_rough(x_rough) and forward_precise(x_precise) with ONE backbone pass over the concatenated batch.
         The reference's step (train.py:397-478) runs the two passes back to back and lets the gradients accumulate;

@@ -48,6 +48,7 @@ class ConvNextBlockLayer(nn.Module):
         return ops.ConvNextLayer.apply(x, dw.weight, dw.bias, norm.weight, norm.bias, fc1.weight, fc1.bias,
                                        fc2.weight, fc2.bias, self.block_scale, mask, torch.is_grad_enabled())
 
+    @torch.jit.unused
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # type: ignore
         c = x.shape[1]
         return helper.act_to_nchw(self.forward_act(helper.nchw_to_act(x, self.compute_dtype)), c)
@@ -78,6 +79,7 @@ class ConvNextBlock(nn.Module):
             x = ops.Conv.apply(feature, self.pconv2x2.weight, self.pconv2x2.bias, 2, 0)
         return feature, x
 
+    @torch.jit.unused
     def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:  # type: ignore
         c = x.shape[1]
         feature, y = self.forward_act(helper.nchw_to_act(x, self.compute_dtype))
@@ -170,6 +172,7 @@ class ConvNext(nn.Module):
             feats.append(feature)
         return feats
 
+    @torch.jit.unused
     def forward(self, x: torch.Tensor) -> List[torch.Tensor]:  # type: ignore
         feats = self.forward_act(x)
         return [helper.act_to_nchw(f, c) for f, c in zip(feats, self.in_channels_group)]

@@ -64,6 +64,7 @@ class FpnNeck(nn.Module):
         outs = [helper.conv_block(o, blk[0], blk[2], 1, 1) for o, blk in zip(outs, self.step2_conv_blocks)]
         return ops.ResizeCat.apply(NEAREST, *outs)  # every level resized to the finest one and concatenated (fpn.py:131-144)
 
+    @torch.jit.unused
     def forward(self, features: List[torch.Tensor]) -> torch.Tensor:  # type: ignore
         acts = [helper.nchw_to_act(f, self.compute_dtype) for f in features]
         return helper.act_to_nchw(self.forward_act(acts), self.out_channels)
@@ -107,5 +108,6 @@ class FpnHead(nn.Module):
         y = ops.Conv.apply(x, proj.weight, proj.bias, 1, 0)
         return ops.ToNchw.apply(y, self.out_channels)
 
+    @torch.jit.unused
     def forward(self, fpn_neck_feature: torch.Tensor) -> torch.Tensor:  # type: ignore
         return self.forward_act(helper.nchw_to_act(fpn_neck_feature, self.compute_dtype))

@@ -26,6 +26,7 @@ class Slot(nn.Module):
     def extra_repr(self):
         return self.what
 
+    @torch.jit.unused
     def forward(self, x):  # never part of the compute path
         raise RuntimeError('Slot modules only keep parameter indices aligned with the reference')
 
@@ -129,4 +130,6 @@ def set_compute_dtype(module: nn.Module, dtype: torch.dtype) -> nn.Module:
     for m in module.modules():
         if hasattr(m, 'compute_dtype'):
             m.compute_dtype = dtype
+        if hasattr(m, '_refresh_script_spec'):  # AdaptiveScaling: the recipe torch.jit.script(model) bakes in
+            m._refresh_script_spec()
     return module

@@ -53,6 +53,7 @@ class PpmBlock(nn.Module):
         cat = ops.ResizeCat.apply(BILINEAR, x, *parts)  # the pooled branches resized to x and concatenated behind it
         return helper.conv_block(cat, self.final_conv_block[0], self.final_conv_block[2], 1, 1)
 
+    @torch.jit.unused
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # type: ignore
         out_c = self.final_conv_block[0].out_channels
         return helper.act_to_nchw(self.forward_act(helper.nchw_to_act(x, self.compute_dtype)), out_c)
@@ -102,6 +103,7 @@ class UperNextNeck(nn.Module):
         # into their channel slices
         return ops.ResizeCat.apply(BILINEAR, *outs)
 
+    @torch.jit.unused
     def forward(self, features: List[torch.Tensor]) -> torch.Tensor:  # type: ignore
         acts = [helper.nchw_to_act(f, self.compute_dtype) for f in features]
         return helper.act_to_nchw(self.forward_act(acts), self.out_channels)
@@ -142,5 +144,6 @@ class UperNextHead(nn.Module):
         y = ops.Conv.apply(x, proj.weight, proj.bias, 1, 0)
         return ops.ToNchw.apply(y, self.out_channels)
 
+    @torch.jit.unused
     def forward(self, fpn_neck_feature: torch.Tensor) -> torch.Tensor:  # type: ignore
         return self.forward_act(helper.nchw_to_act(fpn_neck_feature, self.compute_dtype))
