@@ -45,15 +45,31 @@ constexpr int BK = 64;
 
 // Timing-only ablation switches for profiles/ablate_nt.py (never defined in the shipped build; results are wrong when
 // set): 1 no global loads in the K loop, 2 no LDS staging writes, 4 no barrier, 8 fragments read once, 16 no MFMA,
-// 256 no fused head tail (the staging passes and their barriers stay).
+// 256 no fused head tail (the staging passes and their barriers stay); slab kernel only: 32 every LDS-DMA request out of range
+// (zero fill, no memory access), 64 every request reads the same 1 KB, 128 weight requests confined to a 1 MB window.
 #ifndef VKAS_ABL
 #define VKAS_ABL 0
 #endif
 constexpr int ABL = VKAS_ABL;
-// VKAS_SLAB_V1: the round-2 schedule of conv3x3_slab_mfma_kernel (two wave groups, READ / MFMA phases, two barriers per sub-step),
-// kept for A/B timing (profiles/bench_heads.py against a -DVKAS_SLAB_V1=1 build)
+// Switches of conv3x3_slab_mfma_kernel (all give correct results; A/B builds through profiles/build_variant.sh, measured with
+// profiles/bench_slab.py + profiles/pmc_fetch.sh in round 3 on the fused precise heads, 10.4 ms / 8.4 GB fetched per launch):
+//   1  the slab (activation) requests carry the non-temporal hint                       10.6 ms, 13.5 GB with 4 (rows re-fetched)
+//   2  the weight requests carry it                                                      10.7 ms
+//   4  fused launch of four heads: XCDs 0-3 run heads 0, 1 and XCDs 4-7 heads 2, 3, so that an XCD's L2 (4 MB) holds the
+//      2.7 MB of weights it cycles through instead of thrashing on 5.3 MB                10.4 ms, 7.05 GB   <- shipped
+//   8  the LDS-DMA requests of a READ phase in front of its fragment reads               10.5 ms
+//  32  z leaves with streaming (non-temporal) stores                                     10.5 ms, 8.4 GB (7.03 GB with 4)
+#ifndef VKAS_EXP
+#define VKAS_EXP 4
+#endif
+constexpr int EXPS = VKAS_EXP;
+// VKAS_SLAB_V1 = 1 (shipped): the two-wave-group schedule of conv3x3_slab_mfma_kernel (READ / MFMA phases, two barriers per
+// sub-step).  = 0: the round-3 experiment - one instruction stream per wave, fragments prefetched one pipeline unit ahead, one
+// barrier per sub-step - which measured 8-10 % SLOWER (profiles/bench_slab.py: 4.26 against 3.88 ms on the N = 384, K = 9 x 384
+// shape; without any LDS-DMA 3.67 against 2.99 ms): with the two waves of a SIMD running the same stream their fetches coincide
+// and the matrix cores idle meanwhile, which the phase alternation avoids.  Kept for A/B builds (profiles/build_variant.sh).
 #ifndef VKAS_SLAB_V1
-#define VKAS_SLAB_V1 0
+#define VKAS_SLAB_V1 1
 #endif
 #ifndef VKAS_NOSB
 #define VKAS_SB __builtin_amdgcn_sched_barrier(0)
@@ -132,7 +148,16 @@ __device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head,
   for (int i = 0; i < VPL; ++i) {
     const int c0 = (j + LPR * i) * 8;
     if (c0 >= width) continue;
-    if (m < M && zout) store8(zout + m * e.ldo + n0 + c0, v[i]);  // zout == nullptr: inference, nothing kept for backward
+    if (m < M && zout) {  // zout == nullptr: inference, nothing kept for backward
+      if constexpr ((EXPS & 32) != 0) {  // experiment: streaming store (z is next read by the backward pass, far away)
+        elem8 a;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] = (elem_t)v[i][c];
+        __builtin_nontemporal_store(a, reinterpret_cast<elem8*>(zout + m * e.ldo + n0 + c0));
+      } else {
+        store8(zout + m * e.ldo + n0 + c0, v[i]);
+      }
+    }
     float gm[8], bt[8], a[8];
     load8(hp + c0, gm);
     load8(hp + pw + c0, bt);
@@ -559,8 +584,10 @@ __device__ __forceinline__ void conv3x3_slab_body(const elem_t* __restrict__ x, 
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq) {
         const int q = part * 2 + qq;
-        const unsigned voff = ok ? base + (unsigned)q * a_qstep + step_off : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr)(dst + (q * 8 + wave) * 512), 16, voff, 0, 0, 0);
+        unsigned voff = ok ? base + (unsigned)q * a_qstep + step_off : OOB;
+        if constexpr ((ABL & 32) != 0) voff = OOB;                      // timing only: zero fill, nothing fetched
+        if constexpr ((ABL & 64) != 0) voff = (unsigned)lane * 16u;     // timing only: every request reads the same 1 KB
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr)(dst + (q * 8 + wave) * 512), 16, voff, 0, 0, (EXPS & 1) ? 2 : 0);
       }
     } else {
       const bool ok = row_ok && h_ok && cb * 64 + hcl * 8 < Cp;
@@ -579,8 +606,11 @@ __device__ __forceinline__ void conv3x3_slab_body(const elem_t* __restrict__ x, 
 #pragma unroll
     for (int q = 0; q < NBQ; ++q) {
       if (RAG != 0 && q == NBQ - 1 && wave >= RAG) break;  // wave-uniform
-      const unsigned voff = (c_ok && q * 64 + b_row < b_rows) ? base + (unsigned)q * b_qstep + step_off : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr)(dst + (q * 8 + wave) * 512), 16, voff, 0, 0, 0);
+      unsigned voff = (c_ok && q * 64 + b_row < b_rows) ? base + (unsigned)q * b_qstep + step_off : OOB;
+      if constexpr ((ABL & 32) != 0) voff = OOB;
+      if constexpr ((ABL & 64) != 0) voff = (unsigned)lane * 16u;
+      if constexpr ((ABL & 128) != 0) voff = (unsigned)(q * 8 + wave) * 1024u + (unsigned)lane * 16u + step_off % (1u << 20);  // weights from a 1 MB window
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr)(dst + (q * 8 + wave) * 512), 16, voff, 0, 0, (EXPS & 2) ? 2 : 0);
     }
   };
 
@@ -646,6 +676,20 @@ __device__ __forceinline__ void conv3x3_slab_body(const elem_t* __restrict__ x, 
       // ---- READ phase: share of the next slab, weight tile two sub-steps ahead, this sub-step's fragments
       const lds_elem* Bs = lds + 2 * SLAB + kx * BT;
       elem8 fa[2][TM], fb[2][TN];
+      auto issue_all = [&]() {
+        if constexpr ((ABL & 1) == 0) {
+          if (more) {
+            if constexpr (kx == 0) { issue_a(0, ky1, cb1, sb ^ 1); issue_a(2, ky1, cb1, sb ^ 1); }
+            if constexpr (kx == 1) issue_a(1, ky1, cb1, sb ^ 1);
+          }
+          if constexpr (kx == 0) issue_b(ky, 2, cb, 2);
+          else if (more) issue_b(ky1, kx - 1, cb1, kx - 1);
+        }
+      };
+      if constexpr ((EXPS & 8) != 0) {  // experiment: requests in front of the fragment reads
+        issue_all();
+        asm volatile("" ::: "memory");
+      }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -661,14 +705,7 @@ __device__ __forceinline__ void conv3x3_slab_body(const elem_t* __restrict__ x, 
           fb[h][j] = *(const lds_elem8*)(Bs + swz_off(wn * TN * 16 + j * 16 + frow, h * 4 + fchunk));
       }
       asm volatile("" ::: "memory");  // fragment reads first: their latency hides behind the DMA issue
-      if constexpr ((ABL & 1) == 0) {
-        if (more) {
-          if constexpr (kx == 0) { issue_a(0, ky1, cb1, sb ^ 1); issue_a(2, ky1, cb1, sb ^ 1); }
-          if constexpr (kx == 1) issue_a(1, ky1, cb1, sb ^ 1);
-        }
-        if constexpr (kx == 0) issue_b(ky, 2, cb, 2);
-        else if (more) issue_b(ky1, kx - 1, cb1, kx - 1);
-      }
+      if constexpr ((EXPS & 8) == 0) issue_all();
       if (grp == 1) retire();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if constexpr ((ABL & 4) == 0) __builtin_amdgcn_s_barrier();
@@ -894,7 +931,14 @@ __global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const elem_t* __
   const unsigned total = gridDim.x;
   const unsigned xcd = blockIdx.x & 7u, slot8 = blockIdx.x >> 3;
   const unsigned q8 = total >> 3, r8 = total & 7u;
-  const unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
+  unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
+  if constexpr (HEAD && (EXPS & 4) != 0) {
+    if (ntile_n == 4 && (total & 31u) == 0) {  // whole M tiles per XCD quarter
+      const unsigned mt = total >> 2;                    // M tiles
+      const unsigned m_tile = (xcd & 3u) * (mt >> 2) + (slot8 >> 1);
+      tile = m_tile * 4u + (xcd >> 2) * 2u + (slot8 & 1u);
+    }
+  }
   if constexpr (HEAD && TN == 7) {
     // the launch is sized for its widest head (<= 224 columns); heads of <= 192 columns run the 6-tile body: 1/7 fewer
     // MFMAs and weight bytes for three of the four precise heads
