@@ -29,3 +29,12 @@ def pytest_sessionfinish(session, exitstatus):
     path = parity_log.write_report()
     if path:
         print('\nparity report:', path)
+
+
+def pytest_runtest_logreport(report):
+    """VKAS_TEST_TIMES=<file>: append "<seconds> <phase> <test id>" as each test phase finishes (suite-time budgeting: the
+    driver runs the whole -m gpu suite in one go)."""
+    path = os.environ.get('VKAS_TEST_TIMES')
+    if path and report.duration > 0.5:
+        with open(path, 'a') as f:
+            f.write('%8.1f %-8s %s %s\n' % (report.duration, report.when, report.outcome, report.nodeid))

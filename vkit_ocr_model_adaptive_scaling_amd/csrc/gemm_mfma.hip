@@ -63,19 +63,10 @@ constexpr int ABL = VKAS_ABL;
 #define VKAS_EXP 4
 #endif
 constexpr int EXPS = VKAS_EXP;
-// VKAS_SLAB_V1 = 1 (shipped): the two-wave-group schedule of conv3x3_slab_mfma_kernel (READ / MFMA phases, two barriers per
-// sub-step).  = 0: the round-3 experiment - one instruction stream per wave, fragments prefetched one pipeline unit ahead, one
-// barrier per sub-step - which measured 8-10 % SLOWER (profiles/bench_slab.py: 4.26 against 3.88 ms on the N = 384, K = 9 x 384
-// shape; without any LDS-DMA 3.67 against 2.99 ms): with the two waves of a SIMD running the same stream their fetches coincide
-// and the matrix cores idle meanwhile, which the phase alternation avoids.  Kept for A/B builds (profiles/build_variant.sh).
-#ifndef VKAS_SLAB_V1
-#define VKAS_SLAB_V1 1
-#endif
-#ifndef VKAS_NOSB
-#define VKAS_SB __builtin_amdgcn_sched_barrier(0)
-#else
-#define VKAS_SB
-#endif
+// Round-3 schedule experiments on conv3x3_slab_mfma_kernel / conv3x3_wgrad_slab_kernel (both correct, both SLOWER; kept as a
+// patch with their measurements in profiles/experiments/): a single instruction stream per wave with fragments prefetched one
+// pipeline unit ahead and one barrier per sub-step (4.26 against 3.88 ms on the N = 384, K = 9 x 384 shape), and the LDS-DMA
+// requests paced through the MFMA phases instead of issued back to back in the READ phases (4.80 against 3.95 ms).
 
 // Phase timestamps of gemm_nt_mfma_kernel for profiles/trace_nt.py (-DVKAS_TRACE builds only, never shipped): 8 slots per
 // workgroup - s_memtime at entry, after the prologue barrier, after the K loop, after the epilogue (stores issued), after
@@ -627,17 +618,12 @@ __device__ __forceinline__ void conv3x3_slab_body(const elem_t* __restrict__ x, 
   issue_a(2, 0, 0, 0);
   issue_b(0, 0, 0, 0);
   issue_b(0, 1, 0, 1);
-#if !VKAS_SLAB_V1
-  issue_b(0, 2, 0, 2);
-  if (NS > 1) { issue_a(0, 1, 0, 1); issue_a(2, 1, 0, 1); }  // step 1 = (ky 1, channel block 0)
-#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
   const int frow = lane & 15;
   const int fchunk = lane >> 4;
-#if VKAS_SLAB_V1
   // Two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run half a sub-step apart: every sub-step is a READ
   // phase (issue the LDS-DMA, fetch both K halves of the fragments) and an MFMA phase (48-56 back-to-back MFMAs), each
   // closed by a barrier; group 1 starts one barrier late, so on every SIMD one wave feeds the matrix core while the
@@ -747,176 +733,6 @@ __device__ __forceinline__ void conv3x3_slab_body(const elem_t* __restrict__ x, 
   }
   if (s < NS) step(std::integral_constant<int, 0>{}, s);
   if (grp == 0) __builtin_amdgcn_s_barrier();  // group 1's last MFMA phase: every wave passes the same number of barriers
-#else
-  // Schedule (round 3).  A sub-step (K = 64) is cut into four units: (K half h, column group g) with the wave's TN column
-  // tiles split into two groups.  The fragments a unit needs - the row fragments of its K half, the column fragments of its
-  // group - are fetched while the matrix cores work on the unit before it, so a wave never waits for LDS, there is no separate
-  // READ phase, ONE barrier per sub-step, and only (2 TM + 2 ceil(TN / 2)) fragments are alive at a time instead of 2 (TM + TN)
-  // (round 2: two wave groups alternating READ / MFMA phases, two barriers per sub-step, each costing ~300 cycles of skew on
-  // top of a READ phase as long as the MFMA phase: 1 185 cycles per 770 of matrix work).  Per sub-step j:
-  //   U0 (h0, g0)  fetch columns (h0, g1)                         | MFMAs
-  //   U1 (h0, g1)  fetch rows h1, columns (h1, g0)                | MFMAs
-  //   U2 (h1, g0)  fetch columns (h1, g1)                         | MFMAs | retire the LDS-DMA issued in U3(j-1) | barrier j
-  //   U3 (h1, g1)  issue the LDS-DMA of j (weight tile j+2, a share of the next slab)
-  //                fetch rows h0, columns (h0, g0) of sub-step j+1 | MFMAs
-  // Buffer life times: tile j / the slab are last read by the fetch in U2(j), complete (lgkmcnt(0)) in front of barrier j;
-  // tile j's ring slot is re-filled by the issue of U3(j+1), the slab buffer by U3 of the next step - both behind that barrier.
-  // What U3(j) issues is first read in U3(j+1) resp. later, behind barrier j+1, in front of which every wave has retired its
-  // own share (vmcnt(0): nothing younger is in flight).
-  constexpr int G0 = (TN + 1) / 2, G1 = TN - G0;  // column tiles per group
-  elem8 fa[2][TM], fb[2][G0];
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  // Fragment addresses = a per-lane element offset (10 + 2 registers, below) + a compile-time constant (slab parity, row
-  // group, ring slot, column tile): the XOR key of a slab row, (row & 7), depends on the lane's row inside its 16-row group
-  // and on the tap shift kx - 1 only - spelled out here because the compiler does not see it through the sums and otherwise
-  // keeps one address register per (row group, tap, K half).
-  // (byte addresses; the column fragments get one base per 64 KB of ring: a DS offset field has 16 bits)
-  unsigned la[3][2], la_lo[2], la_hi[2], lb[2], lb2[2];
-  const unsigned lds0 = (unsigned)(uintptr_t)lds;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int c = h * 4 + fchunk;
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int rr = frow + kx - 1;  // -1 .. 16 (row inside the group, shifted by the tap)
-      la[kx][h] = lds0 + (unsigned)(((wm * 64 + rr) * BK + ((c ^ (rr & 7)) << 3)) * 2);
-    }
-    // the two rows outside the 256-pixel tile live in slab rows 256 / 257 (left / right halo)
-    la_lo[h] = (wm == 0 && frow == 0) ? lds0 + (unsigned)((256 * BK + (c << 3)) * 2) : la[0][h];
-    la_hi[h] = (wm == WM - 1 && frow == 15) ? lds0 + (unsigned)(((257 - (TM - 1) * 16) * BK + ((c ^ 1) << 3)) * 2) : la[2][h];
-    lb[h] = lds0 + (unsigned)((2 * SLAB + (wn * TN * 16 + frow) * BK + ((c ^ (frow & 7)) << 3)) * 2);
-    lb2[h] = lb[h] + (unsigned)(2 * BT * 2);
-    // opaque: the constants added below stay immediates of the reads instead of being folded into more base registers
-    asm volatile("" : "+v"(la[0][h]), "+v"(la[1][h]), "+v"(la[2][h]), "+v"(la_lo[h]), "+v"(la_hi[h]), "+v"(lb[h]), "+v"(lb2[h]));
-  }
-  auto fetch_a = [&](auto hc, auto sbc, auto kxc) {
-    constexpr int h = decltype(hc)::value, sb = decltype(sbc)::value, kx = decltype(kxc)::value;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const unsigned lane_off = (kx == 0 && i == 0) ? la_lo[h] : ((kx == 2 && i == TM - 1) ? la_hi[h] : la[kx][h]);
-      fa[h][i] = *(const lds_elem8*)(uintptr_t)(lane_off + (unsigned)((sb * SLAB + i * 16 * BK) * 2));
-    }
-  };
-  auto fetch_b = [&](auto hc, auto gc, auto kxc) {  // group g goes to column set g
-    constexpr int h = decltype(hc)::value, g = decltype(gc)::value, kx = decltype(kxc)::value;
-#pragma unroll
-    for (int jj = 0; jj < (g == 0 ? G0 : G1); ++jj)
-      fb[g][jj] = *(const lds_elem8*)(uintptr_t)((kx == 2 ? lb2[h] : lb[h]) +
-                                                (unsigned)(((kx == 2 ? 0 : kx * BT) + (g * G0 + jj) * 16 * BK) * 2));
-  };
-  auto mfmas = [&](auto hc, auto gc) {
-    constexpr int h = decltype(hc)::value, g = decltype(gc)::value;
-    if constexpr ((ABL & 16) != 0) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[h][i]));
-#pragma unroll
-      for (int jj = 0; jj < (g == 0 ? G0 : G1); ++jj) asm volatile("" ::"v"(fb[g][jj]));
-    } else {
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int jj = 0; jj < (g == 0 ? G0 : G1); ++jj)
-          acc[i][g * G0 + jj] = VKAS_MFMA16(fb[g][jj], fa[h][i], acc[i][g * G0 + jj], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-  };
-  int ky = 0, cb = 0;
-  fetch_a(I0{}, I0{}, I0{});
-  fetch_b(I0{}, I0{}, I0{});
-  // one step = (ky, cb) with its three kx sub-steps; slab parity and kx are compile-time constants (two steps per loop trip)
-#ifdef VKAS_STAG
-  const bool g1 = (wave >> 2) == 1;  // the two waves of a SIMD: waves 4-7 fetch behind a unit's MFMAs, waves 0-3 in front
-#define VKAS_FETCH(...)  if (!g1) { __VA_ARGS__ }
-#define VKAS_FETCH1(...) if (g1) { __VA_ARGS__ }
-#else
-#define VKAS_FETCH(...)  { __VA_ARGS__ }
-#define VKAS_FETCH1(...)
-#endif
-  const int nb = NBQ - ((RAG != 0 && wave >= RAG) ? 1 : 0);  // weight-tile instructions of this wave
-  auto step = [&](auto sbc, int s) {
-    constexpr int sb = decltype(sbc)::value;
-    const bool more = s + 1 < NS, more2 = s + 2 < NS;
-    int ky1 = ky + 1, cb1 = cb;   // K order (channel block, ky, kx): see the note on L2 reuse above
-    if (ky1 == 3) { ky1 = 0; cb1 = cb + 1; }
-    int ky2 = ky1 + 1, cb2 = cb1;
-    if (ky2 == 3) { ky2 = 0; cb2 = cb1 + 1; }
-    auto sub = [&](auto kxc) {
-      constexpr int kx = decltype(kxc)::value;
-      using SB = std::integral_constant<int, sb>;
-      using KX = std::integral_constant<int, kx>;
-      VKAS_FETCH(fetch_b(I0{}, I1{}, KX{});)
-      VKAS_SB;
-      mfmas(I0{}, I0{});
-      VKAS_SB;
-      VKAS_FETCH1(fetch_b(I0{}, I1{}, KX{});)
-      VKAS_FETCH(fetch_a(I1{}, SB{}, KX{}); fetch_b(I1{}, I0{}, KX{});)
-      VKAS_SB;
-      mfmas(I0{}, I1{});
-      VKAS_SB;
-      VKAS_FETCH1(fetch_a(I1{}, SB{}, KX{}); fetch_b(I1{}, I0{}, KX{});)
-      VKAS_FETCH(fetch_b(I1{}, I1{}, KX{});)
-      VKAS_SB;
-      mfmas(I1{}, I0{});
-      VKAS_SB;
-      VKAS_FETCH1(fetch_b(I1{}, I1{}, KX{});)
-      // Retire the LDS-DMA two sub-steps old: what the U3 before this one issued may stay in flight (weight tiles are issued
-      // a whole step, i.e. three sub-steps, ahead of their first read; slab shares two), the rest has to have landed.
-      if constexpr ((ABL & 1) != 0) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      } else if (more) {
-        constexpr int NA = kx == 0 ? 3 : (kx == 1 ? 2 : 0);  // slab instructions of the previous U3 (kx 2 / 0 / 1)
-        if (nb == NBQ) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NA + NBQ) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NA + NBQ - 1) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      }
-      if constexpr ((ABL & 4) == 0) __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if constexpr ((ABL & 1) == 0) {
-        // slab of step s+1: rows 128..255 here (kx 0), rows 0..127 + halo were issued in (s-1, kx 2); slab of step s+2:
-        // rows 0..127 + halo in kx 2 (its buffer - this step's own - is free behind the barrier above)
-        if constexpr (kx == 0) { if (more) issue_a(1, ky1, cb1, sb ^ 1); }
-        if constexpr (kx == 2) { if (more2) { issue_a(0, ky2, cb2, sb); issue_a(2, ky2, cb2, sb); } }
-        if (more) issue_b(ky1, kx, cb1, kx);  // the same tap of the next step, into the ring slot this sub-step just left
-      }
-      // first unit of the next sub-step (unconditionally: behind the last step the values are not used, and a conditional
-      // fetch would keep the old fragments alive next to the new ones)
-      if constexpr (kx < 2) {
-        VKAS_FETCH(fetch_a(I0{}, SB{}, std::integral_constant<int, kx + 1>{}); fetch_b(I0{}, I0{}, std::integral_constant<int, kx + 1>{});)
-      } else {
-        VKAS_FETCH(fetch_a(I0{}, std::integral_constant<int, sb ^ 1>{}, I0{}); fetch_b(I0{}, I0{}, I0{});)
-      }
-      VKAS_SB;
-      mfmas(I1{}, I1{});
-      VKAS_SB;
-      if constexpr (kx < 2) {
-        VKAS_FETCH1(fetch_a(I0{}, SB{}, std::integral_constant<int, kx + 1>{}); fetch_b(I0{}, I0{}, std::integral_constant<int, kx + 1>{});)
-      } else {
-        VKAS_FETCH1(fetch_a(I0{}, std::integral_constant<int, sb ^ 1>{}, I0{}); fetch_b(I0{}, I0{}, I0{});)
-      }
-    };
-    sub(I0{});
-    sub(I1{});
-    sub(I2{});
-    ky = ky1;
-    cb = cb1;
-  };
-  {
-    int s = 0;
-    for (; s + 1 < NS; s += 2) {
-      step(I0{}, s);
-      step(I1{}, s + 1);
-    }
-    if (s < NS) step(I0{}, s);
-  }
-#undef VKAS_FETCH
-#undef VKAS_FETCH1
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();  // (every fragment read is complete: the epilogue re-uses the tile buffers)
-#endif
   nt_epilogue<WM, WN, TM, TN, HEAD>(acc, (float*)lds, e, tile_n, m0, M, n0, n_end, tid);
 }
 
