@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the oracle (fp64 torch on the host) is the slow half of the -m gpu suite: a GPU box reports every core of the machine
+    # while the job owns a 16-core share, and torch's default of one thread per reported core made those tests 10x slower
+    import torch
+    torch.set_num_threads(max(1, min(int(os.environ.get('VKAS_TEST_THREADS', '16')), os.cpu_count() or 1)))
 
 
 def pytest_collection_modifyitems(config, items):

@@ -104,3 +104,27 @@ def test_no_grad_forward_writes_no_backward_operands():
     for a, b in zip(outs_g, outs_n):
         assert torch.equal(a, b)
     assert peak_n < 0.6 * peak_g, (peak_n, peak_g)
+
+
+def test_inferencing_from_a_torchscript_file_matches_the_eager_module(tmp_path):
+    """inferencing/adaptive_scaling.py:85-90 loads a TorchScript file: torch.jit.save(torch.jit.script(model)) of this mirror
+    (fp16 storage, BASELINE.json configs[4]) loaded by path gives the eager module's results bit for bit."""
+    from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
+                                                           AdaptiveScalingNeckHeadType)
+    from vkit_ocr_model_adaptive_scaling_amd.inferencing import AdaptiveScalingInferencing, AdaptiveScalingInferencingConfig
+    model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.TINY, AdaptiveScalingNeckHeadType.UPERNEXT),
+                            compute_dtype=torch.float16)
+    seed_module(model, 72, 0.05)
+    path = str(tmp_path / 'model_jit.pt')
+    torch.jit.save(torch.jit.script(model), path)
+    img = np.random.default_rng(6).integers(0, 256, (90, 140, 3), dtype=np.uint8)
+    eager = AdaptiveScalingInferencing(AdaptiveScalingInferencingConfig(model_jit=model, compute_dtype=torch.float16))
+    a_r, a_p = eager.rough_infer(img), eager.precise_infer(img)
+    del eager, model
+    jit = AdaptiveScalingInferencing(AdaptiveScalingInferencingConfig(model_jit=path))
+    assert isinstance(jit.model, torch.jit.ScriptModule) and not jit.model.training
+    b_r, b_p = jit.rough_infer(img), jit.precise_infer(img)
+    assert np.array_equal(a_r.rough_char_mask, b_r.rough_char_mask)
+    assert np.array_equal(a_r.rough_char_height_score_map, b_r.rough_char_height_score_map)
+    assert np.array_equal(a_p.precise_char_prob_score_map, b_p.precise_char_prob_score_map)
+    assert np.array_equal(a_p.precise_np_char_corner_distance, b_p.precise_np_char_corner_distance)

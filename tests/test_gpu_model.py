@@ -288,8 +288,8 @@ def _bucket_of(name):
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=IDS)
-@pytest.mark.parametrize('init', ['golden', 'reference_init'])
-@pytest.mark.parametrize('kind', ['upernext', 'fpn'])
+@pytest.mark.parametrize('kind,init', [('upernext', 'golden'), ('upernext', 'reference_init'), ('fpn', 'golden')],
+                         ids=['upernext-golden', 'upernext-reference_init', 'fpn-golden'])
 def test_flat_gradient_north_star(kind, init, dtype):
     """BASELINE.json north_star: "loss/grad within 1e-2 bf16" (1e-3 fp32), on the config #1 recipe (1 x 3 x 256 x 256, both
     passes, both losses).  The gradient of the whole step is compared as ONE vector - the flat gradient buffer RCCL reduces
@@ -444,11 +444,14 @@ def test_config2_tiny_backbone_640_batch4(dtype):
     assert max(errs) < FWD_TOL[dtype]
 
 
-_SIZE_CASES = [('base', 'upernext', (96, 160)), ('small', 'fpn', (64, 96)), ('large', 'upernext', (64, 96))]
+_SIZE_CASES = [('base', 'upernext', (96, 160), torch.float32), ('base', 'upernext', (96, 160), torch.bfloat16),
+               ('base', 'upernext', (96, 160), torch.float16),   # configs[4]: Base in fp16
+               ('small', 'fpn', (64, 96), torch.float32), ('small', 'fpn', (64, 96), torch.bfloat16),
+               ('large', 'upernext', (64, 96), torch.float32), ('large', 'upernext', (64, 96), torch.bfloat16)]
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=IDS)
-@pytest.mark.parametrize('size,kind,hw', _SIZE_CASES, ids=[f'{a}-{b}' for a, b, _ in _SIZE_CASES])
+@pytest.mark.parametrize('size,kind,hw,dtype', _SIZE_CASES,
+                         ids=[f'{a}-{b}-{IDS[DTYPES.index(d)]}' for a, b, _, d in _SIZE_CASES])
 def test_model_sizes_nonsquare_vs_oracle(size, kind, hw, dtype):
     """The presets beyond Tiny on a non-square input whose sides are different multiples of 32, both passes, forward + one
     loss backward, vs the oracle, in fp32, bf16 and fp16:

@@ -5,8 +5,9 @@ sigmoid / threshold / softmax / padding-mask post-processing, which runs on the 
 Out of scope: the CPU geometry around it - polygons from masks, text-region flattening / stacking,
 polygon building (vkit, cv2, scipy; third-party code that is absent here).  Images are plain (H, W, 3) uint8 arrays
 instead of ``vkit.element.Image``; results carry numpy arrays instead of ``Mask`` / ``ScoreMap``.  The reference loads
-a TorchScript file (``model_jit``); this mirror takes the ``AdaptiveScaling`` module (or a state-dict file in the
-reference's schema) since its ops are ``autograd.Function``s, not scriptable.
+a TorchScript file (``model_jit``, :85-90); so does this mirror (``torch.jit.save`` of ``torch.jit.script(model)``, see
+model/scripting.py), and it also takes the scripted or the eager ``AdaptiveScaling`` module itself, or a state-dict file in
+the reference's ``RestoreState`` schema.
 """
 import ctypes
 import math
@@ -25,8 +26,11 @@ from ..model import AdaptiveScaling, AdaptiveScalingConfig
 @attrs.define
 class AdaptiveScalingInferencingConfig:
     """inferencing/adaptive_scaling.py:41-58 (tensor-side fields, same names - including the reference's spelling
-    ``legnth`` - and defaults).  ``model_jit`` may be an ``AdaptiveScaling`` module or the path of a state-dict file."""
-    model_jit: Union[str, AdaptiveScaling, None] = None
+    ``legnth`` - and defaults).  ``model_jit``: the path of a TorchScript file (the reference's usage) or of a state-dict
+    file (then ``model_config`` is needed), a scripted module, or an eager ``AdaptiveScaling`` module - which is then
+    switched to eval mode and to ``compute_dtype`` IN PLACE (pass a copy to keep a training module as it is); a scripted
+    module runs in the storage type it was scripted with."""
+    model_jit: Union[str, AdaptiveScaling, torch.jit.ScriptModule, None] = None
     device: str = 'cuda'
     backbone_downsampling_factor: int = 32
     rough_head_upsampling_factor: int = 2
@@ -88,15 +92,21 @@ class AdaptiveScalingInferencing:
         self.config = config
         model = config.model_jit
         if isinstance(model, str):
-            if config.model_config is None:
-                raise ValueError('model_config is required to rebuild the module from a state-dict file')
-            sd = torch.load(model, map_location='cpu', weights_only=True)
-            sd = sd.get('model_jit_state_dict', sd) if isinstance(sd, dict) else sd  # RestoreState schema, train.py:91-96
-            module = AdaptiveScaling(config.model_config)
-            module.load_state_dict(sd)
-            model = module
+            try:  # :85-90: a TorchScript file (the operator it calls is registered by importing this package)
+                model = torch.jit.load(model, map_location=config.device)
+            except RuntimeError:  # not a TorchScript archive: a state-dict / RestoreState file
+                if config.model_config is None:
+                    raise ValueError('model_config is required to rebuild the module from a state-dict file') from None
+                sd = torch.load(model, map_location='cpu', weights_only=True)
+                sd = sd.get('model_jit_state_dict', sd) if isinstance(sd, dict) else sd  # RestoreState schema, train.py:91-96
+                module = AdaptiveScaling(config.model_config)
+                module.load_state_dict(sd)
+                model = module
+        if isinstance(model, torch.jit.ScriptModule):
+            self.model = model.to(config.device).eval()
+            return
         if not isinstance(model, AdaptiveScaling):
-            raise TypeError('config.model_jit must be an AdaptiveScaling module or the path of its state dict')
+            raise TypeError('config.model_jit must be a TorchScript file / module, an AdaptiveScaling module or a state-dict file')
         self.model = model.to(config.device).eval()
         self.model.set_compute_dtype(config.compute_dtype)
 
