@@ -812,7 +812,7 @@ class HeadsFused(Function):
             conv_gemm(x, geom, Bw, Nt, z, _lib.EPI_NONE, bias=b_cat, nk=(sum(cs), C * 9))
             check(lib.vkas_head_tail_fwd(_p(z), Nt, ctypes.byref(head), M, _dt(x), _stream()), 'head_tail_fwd')
         if keep:
-            ctx.save_for_backward(x, z, stats, hp, *ws, *bs)
+            ctx.save_for_backward(x, z, stats, hp, *ws, *bs, *gammas, *betas, *wps, *bps)
         ctx.meta = (cs, ocs, nps, pw, C)
         return tuple(proj[h] for h in range(n_heads))
 
@@ -923,11 +923,41 @@ class HeadsFused(Function):
             else:
                 gws.append(unpack_wgrad(gslice, (cs[h], C, 3, 3), nps[h], Cp))
             gbs.append(gbp[offs[h]:offs[h] + cs[h]])
-        grads = []
+        # the heads' small gradients (conv bias, LayerNorm affine, projection): with flat .grad views they are added in place by
+        # vkas_accumulate_many, 16 contiguous pieces per launch (a projection weight row by row), instead of one autograd add
+        # per parameter (30 launches per step)
+        small = saved[4 + 2 * n_heads:]
+        gammas, betas = small[:n_heads], small[n_heads:2 * n_heads]
+        wps, bps = small[2 * n_heads:3 * n_heads], small[3 * n_heads:4 * n_heads]
+        grads, pieces, delivered = [], [], []
         for h in range(n_heads):
             d = dparams[h]
-            grads.extend([gws[h], gbs[h], d[:cs[h]], d[pw:pw + cs[h]], d[2 * pw:6 * pw].view(4, pw)[:ocs[h], :cs[h]],
-                          d[6 * pw:6 * pw + ocs[h]]])
+            per = [(bs[h], gbs[h], [(gbs[h], 0, cs[h])]), (gammas[h], d[:cs[h]], [(d, 0, cs[h])]),
+                   (betas[h], d[pw:pw + cs[h]], [(d, pw, cs[h])]),
+                   (wps[h], d[2 * pw:6 * pw].view(4, pw)[:ocs[h], :cs[h]], [(d, (2 + q) * pw, cs[h]) for q in range(ocs[h])]),
+                   (bps[h], d[6 * pw:6 * pw + ocs[h]], [(d, 6 * pw, ocs[h])])]
+            out = [gws[h]]
+            for param, g, rows in per:
+                sk = grad_sink(param)
+                if sk is None or not param.grad.is_contiguous():
+                    out.append(g)
+                    continue
+                off = 0
+                for src, so, cnt in rows:
+                    pieces.append((src.data_ptr() + 4 * so, param.grad.data_ptr() + 4 * off, cnt))
+                    off += cnt
+                delivered.append(sk)
+                out.append(None)
+            grads.extend(out)
+        for i in range(0, len(pieces), 16):
+            part = pieces[i:i + 16]
+            n = len(part)
+            src = (ctypes.c_void_p * n)(*[a for a, _, _ in part])
+            dst = (ctypes.c_void_p * n)(*[b for _, b, _ in part])
+            cnt = (ctypes.c_int * n)(*[c for _, _, c in part])
+            check(lib.vkas_accumulate_many(n, src, dst, cnt, _stream()), 'accumulate_many')
+        for sk in delivered:
+            sk[0].grad_delivered(sk[1])
         return (dx, None, *grads)
 
 
