@@ -51,6 +51,18 @@ def main():
         groups[(ev.name, frame.split(pkg)[-1])] += 1
     for (name, frame), c in groups.most_common(60):
         print('%6.1f / step  %-28s %s' % (c / n, name, frame))
+    # runtime copies / memsets and who called them (outermost enclosing CPU op)
+    rt = collections.Counter()
+    for ev in prof.events():
+        if not any(k in ev.name for k in ('Memcpy', 'Memset', 'memcpy', 'memset')):
+            continue
+        par, top = ev.cpu_parent, None
+        while par is not None:
+            top = par
+            par = par.cpu_parent
+        rt[(ev.name[:40], top.name[:60] if top is not None else '-')] += 1
+    for (name, parent), c in rt.most_common(30):
+        print('%6.1f / step  %-40s under %s' % (c / n, name, parent))
 
 
 if __name__ == '__main__':

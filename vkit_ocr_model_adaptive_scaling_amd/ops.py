@@ -145,9 +145,10 @@ def refresh_packed_params():
         return
     keys = tuple(live)
     descs = [d for k in keys for d in live[k][0]]
-    # the uploaded table is valid while the same entries point at the same buffers (an invalidate + lazy rebuild gives the same
-    # keys new images)
-    sig = tuple((d.w, d.out) for d in descs)
+    # the uploaded table is valid while it is byte for byte what would be uploaded now: the same entries pointing at the same
+    # buffers in the same layouts (after an invalidate + lazy rebuild the allocator may hand a freed image block to another
+    # layout of the same weight: equal pointers, different mode)
+    sig = b''.join(bytes(d) for d in descs)
     tab = _PACK_TABLE[0]
     if tab is None or tab[0] != sig:
         arr = (_lib.PackDesc * len(descs))(*descs)

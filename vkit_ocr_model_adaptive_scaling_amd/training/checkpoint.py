@@ -32,12 +32,18 @@ def optimizer_state_dict(optimizer) -> Dict[str, Any]:
     flat: FlatBuffers = optimizer.flat
     state = {}
     if optimizer.step_count > 0:
+        # one copy of each moment buffer to the host, sliced there.  torch.optim.AdamW holds no state for a parameter that never
+        # received a gradient (the fused step skips those too: precise_char_mask_head when disabled, ...); such a parameter's
+        # second moment is still exactly zero everywhere, which is how it is told apart here
+        m1, m2 = optimizer.exp_avg.detach().cpu(), optimizer.exp_avg_sq.detach().cpu()
         for i, n in enumerate(flat.names):
             start, size = flat.offsets[n]
             shape = flat.params[i].shape
+            v = m2[start:start + size]
+            if not bool(v.any()):
+                continue
             state[i] = {'step': torch.tensor(float(optimizer.step_count)),
-                        'exp_avg': optimizer.exp_avg[start:start + size].view(shape).detach().cpu().clone(),
-                        'exp_avg_sq': optimizer.exp_avg_sq[start:start + size].view(shape).detach().cpu().clone()}
+                        'exp_avg': m1[start:start + size].view(shape).clone(), 'exp_avg_sq': v.view(shape).clone()}
     group = {'lr': optimizer.lr, 'betas': tuple(optimizer.betas), 'eps': optimizer.eps, 'weight_decay': optimizer.weight_decay,
              'amsgrad': False, 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
              'initial_lr': optimizer.lr, 'params': list(range(len(flat.names)))}

@@ -107,6 +107,12 @@ def run_training(step, train_batches_of_epoch: Callable[[int], Iterable[Dict]], 
     """``step``: a ``TwoPassStep`` (its optimizer takes the learning rate per call).  ``train_batches_of_epoch(epoch_idx)``
     / ``dev_batches()``: iterables of collated batches (``{'rough': ..., 'precise': ...}``, host tensors)."""
     oc, ec = optimizer_config, epoch_config
+    # the optimizer hyper-parameters of the run are those of its config record (train.py:287-298): applied here so that the
+    # JSON written next to the checkpoints cannot disagree with what trained
+    opt = step.optimizer
+    opt.betas, opt.weight_decay, opt.max_grad_norm = tuple(oc.adamw_betas), oc.adamw_weight_decay, oc.clip_grad_norm_max_norm
+    world = getattr(step, 'world', 1)
+    rank = torch.distributed.get_rank() if (world > 1 and torch.distributed.is_initialized()) else 0
 
     def rule(epoch: float) -> float:
         return cosine_warm_restarts_lr(epoch, oc.adamw_lr, oc.cosine_annealing_warm_restarts_eta_min,
@@ -143,6 +149,10 @@ def run_training(step, train_batches_of_epoch: Callable[[int], Iterable[Dict]], 
             metrics.update(MetricsTag.TRAIN_PRECISE_LOSS, float(p))
         logger.info('Evaluating...')
         dev_rough, dev_precise, dev_loss = evaluate(step, dev_batches(), device, metrics, epoch_idx, ec.dev_num_batches)
+        if world > 1:  # every rank sees its own dev shard: decide "best" on the mean over ranks, identically everywhere
+            t = torch.tensor([dev_rough, dev_precise, dev_loss], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t)
+            dev_rough, dev_precise, dev_loss = (t / world).tolist()
         logger.info(f'E={epoch_idx}, dev_rough_loss = {dev_rough}, dev_precise_loss = {dev_precise}, dev_loss = {dev_loss}')
         if dev_rough < best_rough:
             best_rough = dev_rough
@@ -160,7 +170,8 @@ def run_training(step, train_batches_of_epoch: Callable[[int], Iterable[Dict]], 
                 path = os.path.join(output_folder, f'state_dict_{epoch_idx}_not_best.pt')
             sched = scheduler_state_dict(last_sched_epoch, oc.adamw_lr, oc.cosine_annealing_warm_restarts_eta_min,
                                          oc.cosine_annealing_warm_restarts_t0, oc.cosine_annealing_warm_restarts_tmulti)
-            save_restore_state(path, epoch_idx, step.model, step.optimizer, sched)
+            if rank == 0:  # replicas are identical: one writer
+                save_restore_state(path, epoch_idx, step.model, step.optimizer, sched)
         result = EpochResult(epoch_idx, dev_rough, dev_precise, dev_loss, path)
         results.append(result)
         if on_epoch_end is not None:
