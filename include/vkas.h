@@ -219,6 +219,11 @@ int vkas_resize_fwd(const void* x, long ldx, void* y, long ldy, int B, int Hin, 
 /* dx (+)= resize^T(dy) */
 int vkas_resize_bwd(const void* dy, long lddy, void* dx, long lddx, int B, int Hin, int Win, int Hout, int Wout,
                     int Cp, int mode, int accumulate, int dtype, void* stream);
+/* the same with a workspace (fp32, vkas_resize_bwd_ws_bytes; 0 = none needed): large ratios - the necks' x4 / x8 resize to
+   level-0 size, upernext.py:191-195 - then run as two separable gathers (along x into the workspace, then along y) */
+size_t vkas_resize_bwd_ws_bytes(int B, int Hin, int Win, int Hout, int Wout, int Cp);
+int vkas_resize_bwd_ws(const void* dy, long lddy, void* dx, long lddx, float* ws, size_t ws_bytes, int B, int Hin, int Win,
+                       int Hout, int Wout, int Cp, int mode, int accumulate, int dtype, void* stream);
 
 /* ---- nn.AdaptiveAvgPool2d(s): upernext.py:62 ------------------------------------------------------ */
 int vkas_adaptive_avgpool_fwd(const void* x, long ldx, void* y, long ldy, int B, int H, int W, int s, int Cp,

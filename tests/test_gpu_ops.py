@@ -300,6 +300,30 @@ def test_resize(case, mode, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('mode', [0, 1], ids=['bilinear', 'nearest'])
+@pytest.mark.parametrize('case', [(16, 24, 64, 96), (12, 12, 96, 96), (10, 10, 48, 53), (18, 10, 60, 34)],
+                         ids=['x4', 'x8', 'x4.8-x5.3', 'ragged-x3.3-x3.4'])
+def test_resize_backward_large_ratio_two_pass(case, mode, dtype):
+    """The necks resize levels 2 and 3 to level-0 size by x4 / x8 (upernext.py:191-195, fpn.py:138-142): at these ratios and map
+    sizes the backward runs as two separable gathers through an fp32 workspace (vkas_resize_bwd_ws).  Against torch's own
+    backward of F.interpolate; 96 channels in a 104-channel buffer (pixel stride > channels), ragged non-integer ratios too."""
+    ops = ops_mod()
+    from vkit_ocr_model_adaptive_scaling_amd._lib import lib
+    hi, wi, ho, wo = case
+    B, C = 4, 96
+    assert lib.vkas_resize_bwd_ws_bytes(B, hi, wi, ho, wo, C) == B * ho * wi * C * 4  # the two-pass path is what runs here
+    x = q(rnd((B, C, hi, wi), 50), dtype)
+    xr = x.clone().requires_grad_(True)
+    ref = F.interpolate(xr, size=(ho, wo), mode='bilinear' if mode == 0 else 'nearest')
+    cot = q(rnd(tuple(ref.shape), 51), dtype)
+    (ref * cot).sum().backward()
+    xa = to_act(x, dtype, ld_extra=8).requires_grad_(True)
+    y = ops.Resize.apply(xa, (ho, wo), mode)
+    y.backward(to_act(cot, dtype))
+    close(from_act(xa.grad, C), xr.grad, dtype, 'resize bwd (two-pass)')
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16', 'f16'])
 def test_resize_matches_reference_goldens(dtype):
     """F.interpolate outputs stored by the golden generator (same cases the oracle is pinned on)."""
     ops = ops_mod()

@@ -105,6 +105,9 @@ _SIGS = {
     'vkas_scale_res_bwd_ws_bytes': (c_size_t, [c_long, c_int]),
     'vkas_resize_fwd': (c_int, [_P, c_long, _P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'vkas_resize_bwd': (c_int, [_P, c_long, _P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'vkas_resize_bwd_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    'vkas_resize_bwd_ws': (c_int, [_P, c_long, _P, c_long, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, _P]),
     'vkas_adaptive_avgpool_fwd': (c_int, [_P, c_long, _P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'vkas_adaptive_avgpool_bwd': (c_int, [_P, c_long, _P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'vkas_copy_channels': (c_int, [_P, c_long, _P, c_long, c_long, c_int, c_int, c_int, _P]),

@@ -164,6 +164,78 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ d
   store8(dst, acc);
 }
 
+// Large ratios (the necks' x4 / x8 resize to level-0 size, upernext.py:191-195): a source pixel collects 8 x 8 resp. 16 x 16
+// destinations, so the one-pass gather above has few threads (one per source vector) that each walk 64 - 256 loads in series
+// and every destination vector is fetched by four source pixels: 1.1 TB/s.  Bilinear / nearest weights are separable, so the
+// backward is two gathers: along x (a thread per (destination row, source column) sums its 2r destination columns - contiguous
+// vectors, 16 x more threads) into an fp32 intermediate of Hout x Win pixels, then along y.  Deterministic (no atomics); the
+// products w_y * (sum_x w_x * dy) replace sum_y sum_x (w_y * w_x) * dy, equal up to fp32 rounding.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void resize_bwd_x_kernel(const T* __restrict__ dy, long lddy, float* __restrict__ tmp,
+                                                           int Win, int Wout, int nvec, int mode) {
+  const int idx = blockIdx.y * 256 + threadIdx.x;
+  const int ix = idx / nvec;
+  const int v = idx - ix * nvec;
+  if (ix >= Win) return;
+  const int row = xcd_row(blockIdx.x, gridDim.x);   // b * Hout + oy
+  const float sx = (float)Win / (float)Wout;
+  int ox_lo, ox_hi;
+  dst_range(ix, Win, Wout, sx, mode, ox_lo, ox_hi);
+  const T* rowp = dy + ((long)row * Wout + ox_lo) * lddy + v * 8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    if (ox_lo + j > ox_hi) break;
+    const float w = axis_weight(ox_lo + j, sx, Win, Wout, ix, mode);
+    if (w == 0.f) continue;
+    float t[8];
+    load8(rowp + (long)j * lddy, t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = fmaf(w, t[k], acc[k]);
+  }
+  for (int ox = ox_lo + R; ox <= ox_hi; ++ox) {
+    const float w = axis_weight(ox, sx, Win, Wout, ix, mode);
+    if (w == 0.f) continue;
+    float t[8];
+    load8(dy + ((long)row * Wout + ox) * lddy + v * 8, t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = fmaf(w, t[k], acc[k]);
+  }
+  store8(tmp + ((long)row * Win + ix) * (nvec * 8) + v * 8, acc);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bwd_y_kernel(const float* __restrict__ tmp, T* __restrict__ dx, long lddx,
+                                                           int Hin, int Win, int Hout, int nvec, int mode, int accumulate) {
+  const int idx = blockIdx.y * 256 + threadIdx.x;
+  const int ix = idx / nvec;
+  const int v = idx - ix * nvec;
+  if (ix >= Win) return;
+  const int row = xcd_row(blockIdx.x, gridDim.x);
+  const int b = row / Hin;
+  const int iy = row - b * Hin;
+  const float sy = (float)Hin / (float)Hout;
+  int oy_lo, oy_hi;
+  dst_range(iy, Hin, Hout, sy, mode, oy_lo, oy_hi);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+    const float w = axis_weight(oy, sy, Hin, Hout, iy, mode);
+    if (w == 0.f) continue;
+    float t[8];
+    load8(tmp + (((long)b * Hout + oy) * Win + ix) * (nvec * 8) + v * 8, t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = fmaf(w, t[k], acc[k]);
+  }
+  T* dst = dx + (((long)b * Hin + iy) * Win + ix) * lddx + v * 8;
+  if (accumulate) {
+    float t[8];
+    load8(dst, t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += t[k];
+  }
+  store8(dst, acc);
+}
+
 // ---- exact x2 bilinear (every top-down step and head upsample of upernext.py / fpn.py at the default factors) ---------------
 // out[2i] = 0.25 in[i-1] + 0.75 in[i], out[2i+1] = 0.75 in[i] + 0.25 in[i+1] per axis (borders clamp).  A thread owns one
 // SOURCE pixel vector and writes its 2 x 2 destinations from the 3 x 3 neighbourhood: 9 loads + 4 stores per 4 outputs instead
@@ -419,6 +491,9 @@ static inline unsigned grid_for(long total) {
 
 }  // namespace
 
+extern "C" int vkas_resize_bwd(const void* dy, long lddy, void* dx, long lddx, int B, int Hin, int Win, int Hout,
+                               int Wout, int Cp, int mode, int accumulate, int dtype, void* stream);
+
 static int rs_check(const char* who, const void* a, long lda, const void* b, long ldb, int B, int Hin, int Win, int Hout,
                     int Wout, int Cp) {
   VKAS_CHECK(a && b && vkas_aligned16(a) && vkas_aligned16(b), "%s: null/misaligned tensor", who);
@@ -450,6 +525,40 @@ extern "C" int vkas_resize_fwd(const void* x, long ldx, void* y, long ldy, int B
                                                                mode, accumulate);
   })
   VKAS_LAUNCH_CHECK("resize_fwd");
+  return VKAS_OK;
+}
+
+// the two-pass backward pays when a source pixel has many destinations and the map is large enough to need the threads
+static bool resize_bwd_separable(int B, int Hin, int Win, int Hout, int Wout, int Cp) {
+  static const bool off = getenv("VKAS_RESIZE_NO_SEPARABLE") != nullptr;
+  const bool small = (long)Hin * Win <= 64 && (long)Hout * Wout >= 16L * Hin * Win && Cp / 8 <= 256;
+  return !off && !small && Hout >= 3 * Hin && Wout >= 3 * Win && (long)B * Hout * Wout * (Cp / 8) >= (1L << 16);
+}
+
+extern "C" size_t vkas_resize_bwd_ws_bytes(int B, int Hin, int Win, int Hout, int Wout, int Cp) {
+  return resize_bwd_separable(B, Hin, Win, Hout, Wout, Cp) ? (size_t)B * Hout * Win * Cp * sizeof(float) : 0;
+}
+
+extern "C" int vkas_resize_bwd_ws(const void* dy, long lddy, void* dx, long lddx, float* ws, size_t ws_bytes, int B, int Hin,
+                                  int Win, int Hout, int Wout, int Cp, int mode, int accumulate, int dtype, void* stream) {
+  if (B == 0 || !ws || !resize_bwd_separable(B, Hin, Win, Hout, Wout, Cp))
+    return vkas_resize_bwd(dy, lddy, dx, lddx, B, Hin, Win, Hout, Wout, Cp, mode, accumulate, dtype, stream);
+  int rc = rs_check("vkas_resize_bwd_ws", dy, lddy, dx, lddx, B, Hin, Win, Hout, Wout, Cp);
+  if (rc) return rc;
+  VKAS_CHECK(mode == 0 || mode == 1, "vkas_resize_bwd_ws: bad mode %d", mode);
+  VKAS_CHECK(ws_bytes >= vkas_resize_bwd_ws_bytes(B, Hin, Win, Hout, Wout, Cp) && vkas_aligned16(ws),
+             "vkas_resize_bwd_ws: workspace too small / misaligned");
+  VKAS_CHECK((long)Win * (Cp / 8) < (1L << 30) && vkas_cdiv((long)Win * (Cp / 8), 256) <= 65535, "vkas_resize_bwd_ws: row too wide");
+  const unsigned chunks = (unsigned)vkas_cdiv((long)Win * (Cp / 8), 256);
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_resize_bwd_ws", {
+    dim3 gx((unsigned)((long)B * Hout), chunks), gy((unsigned)((long)B * Hin), chunks);
+    if (2 * vkas_cdiv(Wout, Win) <= 8)
+      resize_bwd_x_kernel<T, 8><<<gx, 256, 0, vkas_stream(stream)>>>((const T*)dy, lddy, ws, Win, Wout, Cp / 8, mode);
+    else
+      resize_bwd_x_kernel<T, 16><<<gx, 256, 0, vkas_stream(stream)>>>((const T*)dy, lddy, ws, Win, Wout, Cp / 8, mode);
+    resize_bwd_y_kernel<T><<<gy, 256, 0, vkas_stream(stream)>>>(ws, (T*)dx, lddx, Hin, Win, Hout, Cp / 8, mode, accumulate);
+  })
+  VKAS_LAUNCH_CHECK("resize_bwd_ws");
   return VKAS_OK;
 }
 

@@ -516,9 +516,12 @@ def resize_bwd(dy, in_size: Tuple[int, int], mode: int):
     dx = new_act(B, Hin, Win, Cp, dy)
     nbytes = B * Cp * dy.element_size() * (Hin * Win + Hout * Wout)
     x2 = mode == 0 and Hout == 2 * Hin and Wout == 2 * Win and Hin > 1 and Win > 1
-    _timed('resize2x_bwd_kernel' if x2 else 'resize_bwd_kernel', dy, 0.0, B * Hout * Wout, Cp, 0,
-           lambda: check(lib.vkas_resize_bwd(_p(dy), act_ld(dy), _p(dx), act_ld(dx), B, Hin, Win, Hout, Wout, Cp, mode, 0,
-                                             _dt(dy), _stream()), 'resize_bwd'), nbytes)
+    wsb = lib.vkas_resize_bwd_ws_bytes(B, Hin, Win, Hout, Wout, Cp)  # > 0: the two-pass (separable) backward of large ratios
+    ws = _ws(wsb, dy.device) if wsb else None
+    name = 'resize2x_bwd_kernel' if x2 else ('resize_bwd_x+y_kernel' if wsb else 'resize_bwd_kernel')
+    _timed(name, dy, 0.0, B * Hout * Wout, Cp, 0,
+           lambda: check(lib.vkas_resize_bwd_ws(_p(dy), act_ld(dy), _p(dx), act_ld(dx), _p(ws), wsb, B, Hin, Win, Hout, Wout, Cp,
+                                                mode, 0, _dt(dy), _stream()), 'resize_bwd'), nbytes)
     return dx
 
 
