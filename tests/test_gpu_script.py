@@ -93,3 +93,44 @@ def test_scripted_module_trains_like_the_eager_one_after_del_model(tmp_path):
         t2 = jit.forward_rough(torch.cat([x] * 4))
     assert torch.equal(t2[0][0], eo[0][0])
     assert t1[0].shape == t2[0].shape
+
+
+def test_train_step_on_the_scripted_module_matches_the_eager_module():
+    """train.py:277-478 end to end on model_jit: script, move, delete the eager module, put the SCRIPTED module's parameters
+    into the flat buffers, run TwoPassStep (the reference's two-pass order: forward_rough / forward_precise of model_jit) with
+    the fused clip + AdamW.  Losses and updated parameters equal those of the same steps on an eager module (the operator's
+    kernel is the same eager code, with direct gradient delivery into the flat buffer and all)."""
+    import gc
+    import bench
+    from vkit_ocr_model_adaptive_scaling_amd.loss_function import (
+        AdaptiveScalingRoughLossFunction, AdaptiveScalingRoughLossFunctionConifg, AdaptiveScalingPreciseLossFunction,
+        AdaptiveScalingPreciseLossFunctionConifg)
+    from vkit_ocr_model_adaptive_scaling_amd.training import FlatBuffers, FlatAdamW, TwoPassStep
+    dev = torch.device('cuda', 0)
+    rough, precise = bench.synthetic_batches(2, (256, 256), dev, 7)
+
+    def run(scripted):
+        m, _, _ = _model('upernext', torch.bfloat16)
+        if scripted:
+            jit = torch.jit.script(m).to(dev)
+            del m
+            gc.collect()
+            m = jit
+        else:
+            m = m.to(dev)
+        m.eval()  # no stochastic depth: the two runs must see the same function
+        flat = FlatBuffers(m.named_parameters())
+        step = TwoPassStep(m, AdaptiveScalingRoughLossFunction(AdaptiveScalingRoughLossFunctionConifg()),
+                           AdaptiveScalingPreciseLossFunction(AdaptiveScalingPreciseLossFunctionConifg()),
+                           FlatAdamW(None, flat=flat), None, merge_backbone=False)
+        p0 = flat.flat_param.detach().clone()
+        losses = [tuple(float(v) for v in step(rough, precise, lr=1e-4)) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert rel_err(flat.flat_param, p0) > 1e-4   # the optimizer moved the scripted module's own parameters
+        return losses, flat.flat_param.detach().clone()
+
+    le, pe = run(False)
+    lj, pj = run(True)
+    assert le[0] == lj[0]                       # first step: identical forward, bit for bit
+    assert all(abs(a - b) <= 1e-4 * abs(a) for x, y in zip(le, lj) for a, b in zip(x, y)), (le, lj)
+    assert rel_err(pj, pe) < 1e-5               # (weight-gradient atomics reorder fp32 sums between runs)
