@@ -33,7 +33,8 @@ _DTYPE_NAMES = {torch.bfloat16: 'bf16', torch.float16: 'f16', torch.float32: 'f3
 _DTYPES = {v: k for k, v in _DTYPE_NAMES.items()}
 
 # eager modules that serve scripted ones: weak references to live modules (scripted from an eager module that still
-# exists) and the modules rebuilt from a spec (owned here; a handful at most - one per scripted / loaded model)
+# exists) and the modules rebuilt from a spec (owned here; a handful at most - one per scripted / loaded model - and each
+# keeps the parameter tensors it was built around alive until it is evicted)
 _LIVE: List['weakref.ReferenceType'] = []
 _REBUILT: Dict[Tuple[str, int], object] = {}
 _MAX_REBUILT = 4
@@ -55,7 +56,8 @@ def register_live(model) -> None:
 
 def _same_tensors(model, params) -> bool:
     own = model._script_params
-    return len(own) == len(params) and all(a is b for a, b in zip(own, params))
+    return (len(own) == len(params) and (not own or own[0] is params[0]) and own[-1] is params[-1]
+            and all(a is b for a, b in zip(own, params)))
 
 
 def _rebuild(spec: str, params):
