@@ -212,7 +212,7 @@ class AdaptiveScaling(nn.Module):
         those of the two separate calls and d(loss_r + loss_p) equals the accumulated gradient.  Halves the number of
         backbone launches and doubles their size (the small stage-3/4 GEMMs fill the 256 CUs better)."""
         b0 = x_rough.shape[0]
-        feats = self.backbone.forward_act(torch.cat([x_rough, x_precise], 0), drop_masks)
+        feats = self.backbone.forward_act((x_rough, x_precise), drop_masks)  # no torch.cat of the images: ops.images_to_act
         halves = [ops.SplitBatch.apply(f, b0) for f in feats]
 
         def rough_branch():

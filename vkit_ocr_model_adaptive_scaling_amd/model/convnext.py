@@ -153,15 +153,20 @@ class ConvNext(nn.Module):
         return [None if layer.prob_bypass == 0.0 else m[i] for i, layer in enumerate(layers)]
 
     def forward_act(self, x: torch.Tensor, masks: Optional[Sequence[Optional[torch.Tensor]]] = None):
-        """x: (B, 3, H, W) raw pixels (fp32 NCHW) -> list of NHWC activations at /4, /8, /16, /32.
+        """x: (B, 3, H, W) raw pixels (fp32 NCHW), or a tuple of such batches of one spatial size (run as one batch)
+        -> list of NHWC activations at /4, /8, /16, /32.
         ``masks``: optional per-layer stochastic-depth keep masks (one (B,) tensor or None per block layer)."""
+        parts = list(x) if isinstance(x, (tuple, list)) else None  # several image batches run as one (forward_both)
+        batch = sum(t.shape[0] for t in parts) if parts is not None else x.shape[0]
+        device = parts[0].device if parts is not None else x.device
         if masks is None:
-            masks = self.draw_stochastic_depth_masks(x.shape[0], x.device)
+            masks = self.draw_stochastic_depth_masks(batch, device)
         pconv, norm = self.stem[0], self.stem[2]
         k = pconv.kernel_size[0]
-        a = ops.ImageToAct.apply(x, self.compute_dtype)
+        want_dx = any(t.requires_grad for t in parts) if parts is not None else x.requires_grad
+        a = ops.images_to_act(parts, self.compute_dtype) if parts is not None else ops.ImageToAct.apply(x, self.compute_dtype)
         # the gradient w.r.t. the image exists only when the caller asks for it (x.requires_grad): training feeds data
-        a = ops.Conv.apply(a, pconv.weight, pconv.bias, k, 0, bool(x.requires_grad and torch.is_grad_enabled()))
+        a = ops.Conv.apply(a, pconv.weight, pconv.bias, k, 0, bool(want_dx and torch.is_grad_enabled()))
         a = ops.LayerNorm.apply(a, norm.weight, norm.bias, False)
         feats = []
         li = 0

@@ -564,6 +564,28 @@ class ImageToAct(Function):
         return out, None
 
 
+def images_to_act(imgs: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
+    """Several (B_i,3,H,W) image batches -> ONE (sum B_i, H, W, 8) activation: the layout conversion of each batch writes its
+    slice of the result, so the merged pass schedule (model.forward_both) needs no torch.cat of the fp32 images (200 MB copied
+    per step at config #3).  Data only: images that require grad take ImageToAct + torch.cat."""
+    if any(i.requires_grad for i in imgs) and torch.is_grad_enabled():
+        return ImageToAct.apply(torch.cat(list(imgs), 0), dtype)
+    _require_cuda(*imgs)
+    H, W = imgs[0].shape[2], imgs[0].shape[3]
+    out = torch.empty((sum(i.shape[0] for i in imgs), H, W, 8), dtype=dtype, device=imgs[0].device)
+    b0 = 0
+    for img in imgs:
+        if img.dim() != 4 or img.shape[2:] != (H, W):
+            raise ValueError('images_to_act: the batches must share their spatial size')
+        img = img.detach()
+        img = (img if img.dtype == _FLOAT else img.float()).contiguous()
+        B, C = img.shape[0], img.shape[1]
+        check(lib.vkas_image_nchw_to_nhwc8(_p(img), _p(out[b0:b0 + B]), B, C, H, W, _dtc(dtype), _stream()),
+              'image_nchw_to_nhwc8')
+        b0 += B
+    return out
+
+
 class Conv(Function):
     """helper.conv1x1 / conv3x3 / pconv2x2 / pconv4x4 (model/helper.py:18-58) as one implicit GEMM.
 
