@@ -98,6 +98,8 @@ __device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head,
   const long m = mrow0 + row;
   const int C = e.head.c[head];
   const int pw = e.head.pw;
+  const int oc = e.head.oc[head];  // projection rows beyond it are zero: not computed (the projection is 8 of a tail's ~27
+                                   // vector operations per element at four rows)
   // hp: this head's gamma | beta | Wproj[4] | bproj(8) | conv bias (pw), copied to LDS once per tile by the caller - every
   // lane re-reads its 8-channel slices of them for every row (14 16-byte loads per vector: from global memory that was
   // 1.5 MB through the L1 per tile and a quarter of the fused kernels' time)
@@ -156,6 +158,7 @@ __device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head,
     for (int c = 0; c < 8; ++c) a[c] = gelu_t<elem_t>((v[i][c] - mean) * rstd * gm[c] + bt[c]);  // pad: gamma = beta = 0
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
+      if (qq >= oc) break;  // workgroup-uniform: the head's out_channels (1 for the rough heads and the probability head)
       float w[8];
       load8(hp + (2 + qq) * pw + c0, w);
 #pragma unroll
@@ -163,8 +166,10 @@ __device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head,
     }
   }
 #pragma unroll
-  for (int qq = 0; qq < 4; ++qq)
+  for (int qq = 0; qq < 4; ++qq) {
+    if (qq >= oc) break;
     pr[qq] = group_sum<LPR>(pr[qq]);
+  }
   if (j == 0 && m < M) {
     const float4 bp = *reinterpret_cast<const float4*>(hp + 6 * pw);
     float* po = e.head.proj + ((long)head * M + m) * 8;
