@@ -100,11 +100,15 @@ __device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head,
   const int pw = e.head.pw;
   const int oc = e.head.oc[head];  // projection rows beyond it are zero: not computed (the projection is 8 of a tail's ~27
                                    // vector operations per element at four rows)
-  // hp: this head's gamma | beta | Wproj[4] | bproj(8) | conv bias (pw), copied to LDS once per tile by the caller - every
-  // lane re-reads its 8-channel slices of them for every row (14 16-byte loads per vector: from global memory that was
-  // 1.5 MB through the L1 per tile and a quarter of the fused kernels' time)
+  // hp: this head's gamma | beta | Wproj[4] | bproj(8), copied to LDS once per tile by the caller - every lane re-reads its
+  // 8-channel slices of them for every row (up to 12 16-byte loads per vector: from global memory that was 1.5 MB through
+  // the L1 per tile and a quarter of the fused kernels' time)
+  // The accumulators already hold conv + bias (the K loop starts from the bias), and a pad column (beyond the head's C
+  // channels) is exactly zero - zero weight rows, zero bias - so sum and sum of squares need no masks; the variance comes from
+  // E[z^2] - mean^2 in fp32 (this epilogue exists in the 16-bit storage modes only: the cancellation error, eps * mean^2 / var,
+  // stays orders below the storage rounding).  3 of the tail's ~21 vector operations per element less.
   float v[VPL][8];
-  float s = 0.f;
+  float s = 0.f, q = 0.f;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int c0 = (j + LPR * i) * 8;
@@ -113,27 +117,19 @@ __device__ __forceinline__ void head_tail_rows(const vkas_epilogue& e, int head,
     if (c0 < width) {
       const float4 lo = *reinterpret_cast<const float4*>(stage + row * EP + c0);
       const float4 hi = *reinterpret_cast<const float4*>(stage + row * EP + c0 + 4);
-      float b[8];
-      load8(hp + 6 * pw + 8 + c0, b);
-      v[i][0] = lo.x + b[0]; v[i][1] = lo.y + b[1]; v[i][2] = lo.z + b[2]; v[i][3] = lo.w + b[3];
-      v[i][4] = hi.x + b[4]; v[i][5] = hi.y + b[5]; v[i][6] = hi.z + b[6]; v[i][7] = hi.w + b[7];
+      v[i][0] = lo.x; v[i][1] = lo.y; v[i][2] = lo.z; v[i][3] = lo.w;
+      v[i][4] = hi.x; v[i][5] = hi.y; v[i][6] = hi.z; v[i][7] = hi.w;
     }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) s += (c0 + c < C) ? v[i][c] : 0.f;
-  }
-  s = group_sum<LPR>(s);
-  const float mean = s / (float)C;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < VPL; ++i) {
-    const int c0 = (j + LPR * i) * 8;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const float d = v[i][c] - mean;
-      q += (c0 + c < C) ? d * d : 0.f;
+      s += v[i][c];
+      q = fmaf(v[i][c], v[i][c], q);
     }
   }
+  s = group_sum<LPR>(s);
   q = group_sum<LPR>(q);
+  const float mean = s / (float)C;
+  q = fmaxf(q - s * mean, 0.f);  // sum of squared deviations
   const float rstd = rsqrtf(q / (float)C + 1e-6f);
   float pr[4] = {0.f, 0.f, 0.f, 0.f};
   elem_t* zout = reinterpret_cast<elem_t*>(e.out);
@@ -236,10 +232,9 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[TM][TN], float* stage, 
     // the head's parameter block and its slice of the conv bias behind the staged rows (visible after the first barrier)
     float* hp_s = stage + ER * EP;
     {
-      const int pw = e.head.pw, PSZ = 6 * pw + 8, width = n_end - n0;
+      const int pw = e.head.pw, PSZ = 6 * pw + 8;
       const float* src = e.head.params + (long)tile_n * PSZ;
-      for (int i = tid; i < PSZ + pw; i += NTHR)
-        hp_s[i] = i < PSZ ? src[i] : ((i - PSZ < width && e.bias) ? e.bias[n0 + i - PSZ] : 0.f);
+      for (int i = tid; i < PSZ; i += NTHR) hp_s[i] = src[i];  // (the conv bias is already in the accumulators)
     }
 #pragma unroll 1
     for (int pass = 0; pass < WM; ++pass) {
@@ -402,9 +397,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const elem_t*
 
   f32x4 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int j = 0; j < TN; ++j) {
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (HEAD) {  // as in conv3x3_slab_body: the fused head tail starts from the bias
+      const int col = n0 + wn * TN * 16 + j * 16 + (lane >> 4) * 4;
+      if (e.bias && col < n_end) b4 = *reinterpret_cast<const f32x4*>(e.bias + col);
+    }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TM; ++i) acc[i][j] = b4;
+  }
 
   const int nk = (K + BK - 1) / BK;
   load_tile();
@@ -612,9 +613,15 @@ __device__ __forceinline__ void conv3x3_slab_body(const elem_t* __restrict__ x, 
 
   f32x4 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int j = 0; j < TN; ++j) {
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (HEAD) {  // the fused head tail wants conv + bias: start from the bias instead of adding it per element later
+      const int col = n0 + wn * TN * 16 + j * 16 + (lane >> 4) * 4;  // lane = 4 consecutive channels of one pixel
+      if (e.bias && col < n_end) b4 = *reinterpret_cast<const f32x4*>(e.bias + col);
+    }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TM; ++i) acc[i][j] = b4;
+  }
 
   const int NCB = (Cp + 63) >> 6;
   const int NS = 3 * NCB;  // steps (ky, cb); three kx sub-steps each
