@@ -130,7 +130,6 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
     float g[R][8], s1[R], s2[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const bool ok = hok && m0 + (long)r * rpi + rl < mend;
       const float d4[4] = {d4v[r].x, d4v[r].y, d4v[r].z, d4v[r].w};
       s1[r] = 0.f;
       s2[r] = 0.f;
@@ -141,7 +140,9 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
       float act[8], gp[8], da[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const float h = ok ? (x[r][c] - mu[r]) * rs[r] * cm[c] : 0.f;
+        // (no validity masks in the sums: a pad channel has gamma = beta = Wproj = 0, so its d(act) and everything derived
+        // from it is zero whatever h is; a row beyond the block has zero statistics and zero d(proj))
+        const float h = (x[r][c] - mu[r]) * rs[r];
         const float u = fmaf(h, gm[c], bt[c]);
         if constexpr (sizeof(T) == 2) {
           float cdf, pdf;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
       }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const float gg = ok ? da[c] * gp[c] * cm[c] : 0.f;
+        const float gg = da[c] * gp[c];
         g[r][c] = gg;
         dg[c] = fmaf(gg, x[r][c], dg[c]);
         db[c] += gg;
