@@ -1168,11 +1168,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const elem_t* _
   for (int i = 0; i < TNn; ++i)
 #pragma unroll
     for (int j = 0; j < TK; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // bias gradient = column sums of dy: wave 0 of the (ky = 0, cb = 0) blocks adds up the dy fragments it holds anyway
-  const bool do_bias = gb != nullptr && ky == 0 && cb == 0 && wave == 0;
-  float bsum[TNn];
-#pragma unroll
-  for (int i = 0; i < TNn; ++i) bsum[i] = 0.f;
+  // bias gradient = column sums of dy: in the (ky = 0, cb = 0) blocks wave w adds up the dy fragments of n tile w (every wave
+  // holds all of them anyway).  One wave summing all eight tiles spent ~250 vector operations per chunk in its MFMA phase,
+  // which - behind the per-chunk barriers - made every ninth workgroup of the launch ~25 % slower than the rest.
+  const bool do_bias = gb != nullptr && ky == 0 && cb == 0 && wave < TNn;
+  float bsum = 0.f;
   // this wave's K-column tiles: columns wave*48 + 16 j of [kx][128 channels]
   int x_shift[TK], x_blk[TK];
 #pragma unroll
@@ -1284,11 +1284,13 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const elem_t* _
     }
     if (do_bias) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int i = 0; i < TNn; ++i) {
+        if (wave != i) continue;  // wave-uniform
 #pragma unroll
-        for (int i = 0; i < TNn; ++i)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int q = 0; q < 8; ++q) bsum[i] += (float)fd[h][i][q];
+          for (int q = 0; q < 8; ++q) bsum += (float)fd[h][i][q];
+      }
     }
     WG_TR(4);
     if (grp == 0) retire();
@@ -1321,14 +1323,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const elem_t* _
     }
   }
   if (do_bias) {  // lanes l, l^16, l^32, l^48 hold different rows of the same column
-#pragma unroll
-    for (int i = 0; i < TNn; ++i) {
-      float v = bsum[i];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      const int n = n0 + i * 16 + (lane & 15);
-      if (lane < 16 && n < Np) atomicAdd(gb + n, v);
-    }
+    float v = bsum;
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    const int n = n0 + wave * 16 + (lane & 15);
+    if (lane < 16 && n < Np) atomicAdd(gb + n, v);
   }
 }
 
