@@ -109,6 +109,15 @@ int vkas_unpack_conv_wgrad(const float* gw, float* grad, int N, int C, int KH, i
 /* dst[k][0..n[k]) += src[k][0..n[k]) for count <= 16 fp32 vectors in one launch: the small per-parameter gradients of a
  * layer (bias, LayerNorm affine, block_scale; what autograd's AccumulateGrad does one launch per tensor) */
 int vkas_accumulate_many(int count, const float* const* src, float* const* dst, const int* n, void* stream);
+/* Up to 8 second-stage column sums in one launch: out[k][c] (+)= sum over the P[k] partial rows (row pitch ldp[k]) of column c <
+   n[k].  vkas_layernorm_bwd / vkas_scale_res_bwd / vkas_dwconv7x7_wgrad called with NULL gradient outputs leave their
+   per-workgroup partial rows in the workspace (vkas_*_parts() rows); the backward of a ConvNeXt layer (convnext.py:29-59) then
+   sums all of them - straight into the parameters' gradient views - with this one launch.  Fixed order: deterministic. */
+int vkas_finalize_many(int count, const float* const* partial, const long* P, const int* n, const int* ldp,
+                       float* const* out, const int* accumulate, void* stream);
+long vkas_layernorm_bwd_parts(long M, int Cp);
+long vkas_scale_res_bwd_parts(long M, int Cp);
+long vkas_dwconv7x7_wgrad_parts(int B, int H, int W, int Cp, int dtype);
 /* v (n) fp32 -> out (np) fp32 zero padded (bias, LayerNorm affine, block_scale) */
 int vkas_pad_vector(const float* v, float* out, int n, int np, void* stream);
 /* depthwise weight (C,1,7,7) fp32 -> vkas_dw_weight_elems(Cp) fp32: (49, Cp) taps x channels followed by the same values

@@ -70,6 +70,11 @@ _SIGS = {
     'vkas_pack_conv_weight_slice': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'vkas_unpack_conv_wgrad': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'vkas_accumulate_many': (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), _P]),
+    'vkas_finalize_many': (c_int, [c_int, POINTER(c_void_p), POINTER(c_long), POINTER(c_int), POINTER(c_int), POINTER(c_void_p),
+                                   POINTER(c_int), _P]),
+    'vkas_layernorm_bwd_parts': (c_long, [c_long, c_int]),
+    'vkas_scale_res_bwd_parts': (c_long, [c_long, c_int]),
+    'vkas_dwconv7x7_wgrad_parts': (c_long, [c_int, c_int, c_int, c_int, c_int]),
     'vkas_pad_vector': (c_int, [_P, _P, c_int, c_int, _P]),
     'vkas_dw_weight_elems': (c_size_t, [c_int]),
     'vkas_pack_dw_weight': (c_int, [_P, _P, c_int, c_int, c_int, _P]),

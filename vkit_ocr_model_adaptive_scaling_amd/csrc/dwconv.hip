@@ -954,6 +954,12 @@ extern "C" size_t vkas_dwconv7x7_wgrad_ws_bytes(int B, int H, int W, int Cp) {
   return (size_t)parts * 50 * (size_t)Cp * sizeof(float);
 }
 
+extern "C" long vkas_dwconv7x7_wgrad_parts(int B, int H, int W, int Cp, int dtype) {  // partial rows the launch leaves in ws
+  if (B == 0) return 0;
+  static const bool valu = getenv("VKAS_DW_VALU") != nullptr;
+  return ((dtype == VKAS_BF16 || dtype == VKAS_F16) && !valu) ? dw_mfma_walkers(B, H, W, Cp) : dw_wgrad_parts(B, H, W);
+}
+
 extern "C" int vkas_dwconv7x7_wgrad(const void* x, long ldx, const void* dy, long lddy, float* gw, float* gb,
                                     float* ws, size_t ws_bytes, int B, int H, int W, int Cp, int dtype,
                                     void* stream) {
@@ -961,12 +967,14 @@ extern "C" int vkas_dwconv7x7_wgrad(const void* x, long ldx, const void* dy, lon
   if (rc) return rc;
   rc = dw_check("vkas_dwconv7x7_wgrad(dy)", dy, lddy, B, H, W, Cp);
   if (rc) return rc;
-  VKAS_CHECK(gw && gb && ws, "vkas_dwconv7x7_wgrad: null output/workspace");
+  VKAS_CHECK(ws && (gw != nullptr) == (gb != nullptr), "vkas_dwconv7x7_wgrad: null output/workspace");
   VKAS_CHECK(ws_bytes >= vkas_dwconv7x7_wgrad_ws_bytes(B, H, W, Cp), "vkas_dwconv7x7_wgrad: workspace too small");
   hipStream_t st = vkas_stream(stream);
   if (B == 0) {
-    (void)hipMemsetAsync(gw, 0, 49L * Cp * sizeof(float), st);
-    (void)hipMemsetAsync(gb, 0, (long)Cp * sizeof(float), st);
+    if (gw) {
+      (void)hipMemsetAsync(gw, 0, 49L * Cp * sizeof(float), st);
+      (void)hipMemsetAsync(gb, 0, (long)Cp * sizeof(float), st);
+    }
     return VKAS_OK;
   }
   static const bool valu = getenv("VKAS_DW_VALU") != nullptr;  // A/B switch: the round-1 vector-ALU kernel
@@ -983,6 +991,7 @@ extern "C" int vkas_dwconv7x7_wgrad(const void* x, long ldx, const void* dy, lon
       dwconv7x7_wgrad_mfma_kernel<f16_t><<<grid, 512, 0, st>>>((const f16_t*)x, ldx, (const f16_t*)dy, lddy, ws, B, H, W, Cp,
                                                               cslices, tiles_x, tiles_y, (int)wps);
     VKAS_LAUNCH_CHECK("dwconv7x7_wgrad_mfma");
+    if (!gw) return VKAS_OK;  // partial rows (50 Cp floats: 49 Cp weights | Cp bias) stay in ws: vkas_dwconv7x7_wgrad_parts
     if (gb == gw + 49L * Cp) return vkas_colreduce_finalize(ws, wps, 50 * Cp, 50 * Cp, gw, 0, st);
     rc = vkas_colreduce_finalize(ws, wps, 49 * Cp, 50 * Cp, gw, 0, st);
     if (rc) return rc;
@@ -997,6 +1006,7 @@ extern "C" int vkas_dwconv7x7_wgrad(const void* x, long ldx, const void* dy, lon
     dwconv7x7_wgrad_kernel<T><<<grid, 256, 0, st>>>((const T*)x, ldx, (const T*)dy, lddy, ws, H, W, Cp, cslices);
   })
   VKAS_LAUNCH_CHECK("dwconv7x7_wgrad");
+  if (!gw) return VKAS_OK;
   if (gb == gw + 49L * Cp) return vkas_colreduce_finalize(ws, P, 50 * Cp, 50 * Cp, gw, 0, st);  // one launch
   rc = vkas_colreduce_finalize(ws, P, 49 * Cp, 50 * Cp, gw, 0, st);
   if (rc) return rc;

@@ -221,6 +221,77 @@ __global__ __launch_bounds__(256) void vkas_colreduce_finalize_kernel(const floa
   }
 }
 
+// Up to 8 column reductions in one launch (the three second-stage sums of a ConvNeXt layer's backward + their delivery into
+// the flat gradient views used to be 3 finalize launches + 1 accumulate launch per layer): block b belongs to reduction k with
+// first[k] <= b < first[k + 1] and sums 16 columns of it exactly as vkas_colreduce_finalize_kernel does.
+struct FinalizeMany {
+  const float* partial[8];
+  float* out[8];
+  long P[8];
+  int n[8], ldp[8], accumulate[8], first[9];
+};
+__global__ __launch_bounds__(256) void vkas_finalize_many_kernel(FinalizeMany a) {
+  __shared__ float red[16][17];
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i) k += ((int)blockIdx.x >= a.first[i]) ? 1 : 0;
+  const float* __restrict__ partial = a.partial[k];
+  const long P = a.P[k];
+  const int n = a.n[k], ldp = a.ldp[k];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = ((int)blockIdx.x - a.first[k]) * 16 + cl;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  if (c < n) {
+    long p = rl;
+    for (; p + 7 * 16 < P; p += 8 * 16) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += partial[(p + 16 * i) * ldp + c];
+    }
+    for (; p < P; p += 16) acc[0] += partial[p * ldp + c];
+  }
+  red[rl][cl] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (rl == 0 && c < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += red[r][cl];
+    float* out = a.out[k];
+    out[c] = a.accumulate[k] ? out[c] + s : s;
+  }
+}
+
+extern "C" int vkas_finalize_many(int count, const float* const* partial, const long* P, const int* n, const int* ldp,
+                                  float* const* out, const int* accumulate, void* stream) {
+  VKAS_CHECK(count >= 0 && count <= 8 && (count == 0 || (partial && P && n && ldp && out && accumulate)),
+             "vkas_finalize_many: bad arguments (count=%d)", count);
+  if (count == 0) return VKAS_OK;
+  FinalizeMany a;
+  int blocks = 0;
+  for (int k = 0; k < 8; ++k) {
+    a.first[k] = blocks;
+    if (k < count) {
+      VKAS_CHECK(partial[k] && out[k] && P[k] >= 0 && n[k] >= 0 && ldp[k] >= n[k], "vkas_finalize_many: bad reduction %d", k);
+      a.partial[k] = partial[k];
+      a.out[k] = out[k];
+      a.P[k] = P[k];
+      a.n[k] = n[k];
+      a.ldp[k] = ldp[k];
+      a.accumulate[k] = accumulate[k];
+      blocks += (int)vkas_cdiv(n[k], 16);
+    } else {
+      a.partial[k] = nullptr; a.out[k] = nullptr; a.P[k] = 0; a.n[k] = 0; a.ldp[k] = 0; a.accumulate[k] = 0;
+    }
+  }
+  a.first[8] = blocks;
+  for (int k = count; k < 8; ++k) a.first[k] = blocks;  // no block maps to an unused slot
+  if (blocks == 0) return VKAS_OK;
+  vkas_finalize_many_kernel<<<(unsigned)blocks, 256, 0, vkas_stream(stream)>>>(a);
+  VKAS_LAUNCH_CHECK("finalize_many");
+  return VKAS_OK;
+}
+
 int vkas_colreduce_finalize(const float* partial, long P, int n, int ldp, float* out, int accumulate,
                             hipStream_t st) {
   vkas_colreduce_finalize_kernel<<<(unsigned)vkas_cdiv(n, 16), 256, 0, st>>>(partial, P, n, ldp, out, accumulate);

@@ -335,11 +335,18 @@ extern "C" size_t vkas_layernorm_bwd_ws_bytes(long M, int Cp) {
   return (size_t)vkas_cdiv(M > 0 ? M : 1, rpb) * 2 * (size_t)Cp * sizeof(float);
 }
 
+extern "C" long vkas_layernorm_bwd_parts(long M, int Cp) {  // partial rows (2 Cp floats each: dgamma | dbeta) left in ws
+  if (M <= 0) return 0;
+  const int G = pick_group(Cp >> 3);
+  return vkas_cdiv(M, rows_per_block_for(M, 2 * (256 / G)));
+}
+
 extern "C" int vkas_layernorm_bwd(const void* x, long ldx, const float* gamma, const float* beta, const float* stats,
                                   const void* dy, long lddy, void* dx, long lddx, float* dgamma, float* dbeta,
                                   float* ws, size_t ws_bytes, long M, int C, int Cp, int act_gelu, int dtype,
                                   void* stream) {
-  VKAS_CHECK(x && dy && dx && gamma && beta && stats && dgamma && dbeta && ws, "vkas_layernorm_bwd: null pointer");
+  VKAS_CHECK(x && dy && dx && gamma && beta && stats && ws && (dgamma != nullptr) == (dbeta != nullptr),
+             "vkas_layernorm_bwd: null pointer");
   VKAS_CHECK(Cp > 0 && Cp % 8 == 0 && Cp <= 2048 && C > 0 && C <= Cp, "vkas_layernorm_bwd: bad C=%d Cp=%d", C, Cp);
   VKAS_CHECK(ldx >= Cp && lddy >= Cp && lddx >= Cp && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 &&
                  vkas_aligned16(x) && vkas_aligned16(dy) && vkas_aligned16(dx),
@@ -347,8 +354,10 @@ extern "C" int vkas_layernorm_bwd(const void* x, long ldx, const float* gamma, c
   VKAS_CHECK(ws_bytes >= vkas_layernorm_bwd_ws_bytes(M, Cp), "vkas_layernorm_bwd: workspace too small");
   hipStream_t st = vkas_stream(stream);
   if (M <= 0) {
-    (void)hipMemsetAsync(dgamma, 0, Cp * sizeof(float), st);
-    (void)hipMemsetAsync(dbeta, 0, Cp * sizeof(float), st);
+    if (dgamma) {
+      (void)hipMemsetAsync(dgamma, 0, Cp * sizeof(float), st);
+      (void)hipMemsetAsync(dbeta, 0, Cp * sizeof(float), st);
+    }
     return VKAS_OK;
   }
   const int G = pick_group(Cp >> 3);
@@ -367,6 +376,7 @@ extern "C" int vkas_layernorm_bwd(const void* x, long ldx, const float* gamma, c
                                                               (T*)dx, lddx, ws, M, C, Cp, G, act_gelu, rpb);
   })
   VKAS_LAUNCH_CHECK("layernorm_bwd");
+  if (!dgamma) return VKAS_OK;  // the caller sums the vkas_layernorm_bwd_parts() partial rows itself (vkas_finalize_many)
   if (dbeta == dgamma + Cp) return vkas_colreduce_finalize(ws, P, 2 * Cp, 2 * Cp, dgamma, 0, st);  // one launch
   int rc = vkas_colreduce_finalize(ws, P, Cp, 2 * Cp, dgamma, 0, st);
   if (rc) return rc;
@@ -378,10 +388,15 @@ extern "C" size_t vkas_scale_res_bwd_ws_bytes(long M, int Cp) {
   return (size_t)vkas_cdiv(M > 0 ? M : 1, rpb) * 2 * (size_t)Cp * sizeof(float);
 }
 
+extern "C" long vkas_scale_res_bwd_parts(long M, int Cp) {
+  (void)Cp;
+  return M <= 0 ? 0 : vkas_cdiv(M, rows_per_block_for(M, 1));
+}
+
 extern "C" int vkas_scale_res_bwd(const void* dout, long lddo, const void* z, long ldz, const float* colscale,
                                   const float* rowscale, int rows_per_image, void* dz, long lddz, float* dscale,
                                   float* dbias, float* ws, size_t ws_bytes, long M, int Cp, int dtype, void* stream) {
-  VKAS_CHECK(dout && z && colscale && dz && dscale && dbias && ws, "vkas_scale_res_bwd: null pointer");
+  VKAS_CHECK(dout && z && colscale && dz && ws && (dscale != nullptr) == (dbias != nullptr), "vkas_scale_res_bwd: null pointer");
   VKAS_CHECK(Cp > 0 && Cp % 8 == 0 && Cp <= 2048 && rows_per_image > 0, "vkas_scale_res_bwd: bad Cp=%d", Cp);
   VKAS_CHECK(lddo >= Cp && ldz >= Cp && lddz >= Cp && lddo % 8 == 0 && ldz % 8 == 0 && lddz % 8 == 0 &&
                  vkas_aligned16(dout) && vkas_aligned16(z) && vkas_aligned16(dz),
@@ -391,8 +406,10 @@ extern "C" int vkas_scale_res_bwd(const void* dout, long lddo, const void* z, lo
   VKAS_CHECK(ws_bytes >= (size_t)P * 2 * Cp * sizeof(float), "vkas_scale_res_bwd: workspace too small");
   hipStream_t st = vkas_stream(stream);
   if (M <= 0) {
-    (void)hipMemsetAsync(dscale, 0, Cp * sizeof(float), st);
-    (void)hipMemsetAsync(dbias, 0, Cp * sizeof(float), st);
+    if (dscale) {
+      (void)hipMemsetAsync(dscale, 0, Cp * sizeof(float), st);
+      (void)hipMemsetAsync(dbias, 0, Cp * sizeof(float), st);
+    }
     return VKAS_OK;
   }
   VKAS_DISPATCH_DTYPE(dtype, "vkas_scale_res_bwd", {
@@ -400,6 +417,7 @@ extern "C" int vkas_scale_res_bwd(const void* dout, long lddo, const void* z, lo
                                                          rows_per_image, (T*)dz, lddz, ws, M, Cp, rpb);
   })
   VKAS_LAUNCH_CHECK("scale_res_bwd");
+  if (!dscale) return VKAS_OK;  // partial rows stay in ws (vkas_scale_res_bwd_parts of them, 2 Cp floats: dscale | dbias)
   if (dbias == dscale + Cp) return vkas_colreduce_finalize(ws, P, 2 * Cp, 2 * Cp, dscale, 0, st);  // one launch
   int rc = vkas_colreduce_finalize(ws, P, Cp, 2 * Cp, dscale, 0, st);
   if (rc) return rc;

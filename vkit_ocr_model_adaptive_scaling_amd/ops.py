@@ -483,19 +483,57 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, C: i
     return y, stats
 
 
-def layernorm_bwd(x, gamma, beta, stats, dy, C: int, act_gelu: bool):
+def layernorm_bwd(x, gamma, beta, stats, dy, C: int, act_gelu: bool, defer: bool = False):
+    """defer: leave the per-workgroup partial rows of dgamma | dbeta in the workspace and return (dx, ws, parts) - the caller
+    sums them (finalize_many), typically straight into the parameters' gradient views."""
     B, H, W, Cp = x.shape
     M = B * H * W
     dx = new_act(B, H, W, Cp, x)
-    dgb = torch.empty((2 * Cp,), dtype=_FLOAT, device=x.device)  # contiguous pair -> one finalize launch
-    dg, db = dgb[:Cp], dgb[Cp:]
     nbytes = lib.vkas_layernorm_bwd_ws_bytes(M, Cp)
     ws = _ws(nbytes, x.device)
     gamma, beta = pad_vector(gamma, Cp), pad_vector(beta, Cp)
+    if defer:
+        check(lib.vkas_layernorm_bwd(_p(x), act_ld(x), _p(gamma), _p(beta), _p(stats), _p(dy), act_ld(dy), _p(dx),
+                                     act_ld(dx), None, None, _p(ws), nbytes, M, C, Cp, int(act_gelu), _dt(x),
+                                     _stream()), 'layernorm_bwd')
+        return dx, ws, lib.vkas_layernorm_bwd_parts(M, Cp)
+    dgb = torch.empty((2 * Cp,), dtype=_FLOAT, device=x.device)  # contiguous pair -> one finalize launch
+    dg, db = dgb[:Cp], dgb[Cp:]
     check(lib.vkas_layernorm_bwd(_p(x), act_ld(x), _p(gamma), _p(beta), _p(stats), _p(dy), act_ld(dy), _p(dx),
                                  act_ld(dx), _p(dg), _p(db), _p(ws), nbytes, M, C, Cp, int(act_gelu), _dt(x),
                                  _stream()), 'layernorm_bwd')
     return dx, dg[:C], db[:C]
+
+
+_NO_FINALIZE_MANY = os.environ.get('VKAS_NO_FINALIZE_MANY') is not None  # A/B switch: per-op finalize + accumulate launches
+
+
+def finalize_many(items):
+    """items: [(workspace tensor, first column, partial rows, columns, row pitch, out tensor, accumulate)] -> ONE launch of
+    vkas_finalize_many per 8 reductions (second-stage column sums, optionally added onto ``out``)."""
+    for i in range(0, len(items), 8):
+        part = items[i:i + 8]
+        n = len(part)
+        src = (ctypes.c_void_p * n)(*[ws.data_ptr() + 4 * col for ws, col, _, _, _, _, _ in part])
+        P = (ctypes.c_long * n)(*[p for _, _, p, _, _, _, _ in part])
+        nn = (ctypes.c_int * n)(*[c for _, _, _, c, _, _, _ in part])
+        ld = (ctypes.c_int * n)(*[l for _, _, _, _, l, _, _ in part])
+        dst = (ctypes.c_void_p * n)(*[o.data_ptr() for _, _, _, _, _, o, _ in part])
+        acc = (ctypes.c_int * n)(*[int(a) for _, _, _, _, _, _, a in part])
+        check(lib.vkas_finalize_many(n, src, P, nn, ld, dst, acc, _stream()), 'finalize_many')
+
+
+def small_grad_views(params, Cp: int):
+    """The parameters' flat gradient views if EVERY one of them can take a Cp-wide column sum directly (FlatBuffers attached,
+    no channel padding), else None."""
+    if _NO_FINALIZE_MANY:
+        return None
+    sinks = [grad_sink(p) for p in params]
+    if any(s is None for s in sinks):
+        return None
+    if any(p.numel() != Cp or not p.grad.is_contiguous() or p.grad.dtype != _FLOAT for p in params):
+        return None
+    return sinks
 
 
 def resize_fwd(x, size: Tuple[int, int], mode: int, out=None, accumulate=False):
@@ -659,6 +697,15 @@ class LayerNorm(Function):
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, stats = ctx.saved_tensors
+        sinks = small_grad_views((gamma, beta), x.shape[3])
+        if sinks is not None:  # the column sums go straight into the gradient views: one launch instead of finalize + add
+            Cp = x.shape[3]
+            dx, ws, parts = layernorm_bwd(x, gamma.contiguous(), beta.contiguous(), stats, as_act(dy), gamma.numel(),
+                                          ctx.act_gelu, defer=True)
+            finalize_many([(ws, 0, parts, Cp, 2 * Cp, gamma.grad, True), (ws, Cp, parts, Cp, 2 * Cp, beta.grad, True)])
+            for sk in sinks:
+                sk[0].grad_delivered(sk[1])
+            return dx, None, None, None
         dx, dg, db = layernorm_bwd(x, gamma.contiguous(), beta.contiguous(), stats, as_act(dy), gamma.numel(),
                                    ctx.act_gelu)
         dg, db = deliver_small_grads([(gamma, dg), (beta, db)])
@@ -1260,14 +1307,21 @@ class ConvNextLayer(Function):
         M = B * H * W
         dt, st, dev = _dt(x), _stream(), x.device
         cs = pad_vector(block_scale, Cp)
+        # With flat gradient views on all five small parameters of the layer, the three second-stage column sums of this
+        # backward (layer scale / b2, LayerNorm affine, depthwise weight / bias) and their delivery are ONE vkas_finalize_many
+        # launch at the end instead of three finalize launches + one accumulate launch: the producers leave their partial rows.
+        sinks = small_grad_views((block_scale, b2, ln_g, ln_b, dw_b), Cp)
         # out = x + rs*cs*z  ->  dz, d(block_scale), d(b2)
         dz = new_act(B, H, W, Cp, x)
-        dsb = torch.empty((2 * Cp,), dtype=_FLOAT, device=dev)
-        dscale, db2 = dsb[:Cp], dsb[Cp:]
         nbytes = lib.vkas_scale_res_bwd_ws_bytes(M, Cp)
-        ws = _ws(nbytes, dev)
+        ws_sr = _ws(nbytes, dev)
+        if sinks is None:
+            dsb = torch.empty((2 * Cp,), dtype=_FLOAT, device=dev)
+            dscale, db2 = dsb[:Cp], dsb[Cp:]
+        else:
+            dscale = db2 = None
         check(lib.vkas_scale_res_bwd(_p(dout), act_ld(dout), _p(z), Cp, _p(cs), _p(rs), H * W, _p(dz), Cp, _p(dscale),
-                                     _p(db2), _p(ws), nbytes, M, Cp, dt, st), 'scale_res_bwd')
+                                     _p(db2), _p(ws_sr), nbytes, M, Cp, dt, st), 'scale_res_bwd')
         g2 = _geom(B, H, W, H, W, C4p, C4p, 1, 1, 1, 0)
         g1 = _geom(B, H, W, H, W, Cp, Cp, 1, 1, 1, 0)
         if ctx.chain:
@@ -1292,7 +1346,11 @@ class ConvNextLayer(Function):
             dyn = new_act(B, H, W, Cp, x)
             conv_gemm(dh, g2, pack_conv_weight(w1, C4p, Cp, 1, x.dtype), Cp, dyn, _lib.EPI_NONE)
         # LayerNorm
-        dy, dlg, dlb = layernorm_bwd(y, ln_g.contiguous(), ln_b.contiguous(), stats, dyn, C, False)
+        if sinks is None:
+            dy, dlg, dlb = layernorm_bwd(y, ln_g.contiguous(), ln_b.contiguous(), stats, dyn, C, False)
+        else:
+            dy, ws_ln, parts_ln = layernorm_bwd(y, ln_g.contiguous(), ln_b.contiguous(), stats, dyn, C, False, defer=True)
+            dlg = dlb = None
         # depthwise: wgrad, then dgrad (+ the residual path) in one kernel
         gdwb = torch.empty((50 * Cp,), dtype=_FLOAT, device=dev)
         gdw, gdb = gdwb[:49 * Cp], gdwb[49 * Cp:]
@@ -1300,8 +1358,17 @@ class ConvNextLayer(Function):
         ws = _ws(nbytes, dev)
         mfma = x.dtype in _MFMA_DTYPES
         _timed('dwconv7x7_wgrad_mfma_kernel' if mfma else 'dwconv7x7_wgrad_kernel', x, 2.0 * 49 * M * C, M, Cp, 49,
-               lambda: check(lib.vkas_dwconv7x7_wgrad(_p(x), act_ld(x), _p(dy), Cp, _p(gdw), _p(gdb), _p(ws), nbytes, B, H, W,
+               lambda: check(lib.vkas_dwconv7x7_wgrad(_p(x), act_ld(x), _p(dy), Cp, _p(gdw) if sinks is None else None,
+                                                      _p(gdb) if sinks is None else None, _p(ws), nbytes, B, H, W,
                                                       Cp, dt, st), 'dwconv7x7_wgrad'), 2.0 * M * Cp * x.element_size())
+        if sinks is not None:
+            p_sr = lib.vkas_scale_res_bwd_parts(M, Cp)
+            p_dw = lib.vkas_dwconv7x7_wgrad_parts(B, H, W, Cp, dt)
+            finalize_many([(ws_sr, 0, p_sr, Cp, 2 * Cp, block_scale.grad, True), (ws_sr, Cp, p_sr, Cp, 2 * Cp, b2.grad, True),
+                           (ws_ln, 0, parts_ln, Cp, 2 * Cp, ln_g.grad, True), (ws_ln, Cp, parts_ln, Cp, 2 * Cp, ln_b.grad, True),
+                           (ws, 0, p_dw, 49 * Cp, 50 * Cp, gdw, False), (ws, 49 * Cp, p_dw, Cp, 50 * Cp, dw_b.grad, True)])
+            for sk in sinks:
+                sk[0].grad_delivered(sk[1])
         sdw = grad_sink(dw_w)
         if sdw is not None:  # unpack straight onto the flat gradient view
             check(lib.vkas_unpack_dw_wgrad(_p(gdw), _p(dw_w.grad), C, Cp, 1, st), 'unpack_dw_wgrad')
@@ -1317,6 +1384,8 @@ class ConvNextLayer(Function):
             _timed('dwconv7x7_mfma_kernel' if mfma else 'dwconv7x7_fwd_kernel', x, 2.0 * 49 * M * C, M, Cp, 49,
                    lambda: check(lib.vkas_dwconv7x7_fwd(_p(dy), Cp, _p(wflip), None, _p(dout), act_ld(dout), _p(dx), Cp, B, H,
                                                         W, Cp, dt, st), 'dwconv7x7_dgrad'), 3.0 * M * Cp * x.element_size())
+        if sinks is not None:
+            return (dx, gdw_ref, None, None, None, gw1, db1, gw2, None, None, None, None)
         gdb_, dlg, dlb, db2_, dsc = deliver_small_grads([(dw_b, gdb[:C]), (ln_g, dlg), (ln_b, dlb), (b2, db2[:C]),
                                                          (block_scale, dscale[:C].view(block_scale.shape))])
         return (dx, gdw_ref, gdb_, dlg, dlb, gw1, db1, gw2, db2_, dsc, None, None)
