@@ -269,6 +269,10 @@ typedef struct vkas_precise_loss_cfg {
   float smooth_beta;                                                       /* 2.5, :159-165 */
   float out_scale;
 } vkas_precise_loss_cfg;
+/* margin[0] = min over the n label points of min(py, H-1-py, px, W-1-px): negative iff a point lies outside the (H, W) map.
+ * The reference's advanced indexing (loss_function/adaptive_scaling.py:235-262) raises for such a point; the host reads this
+ * value asynchronously instead of synchronising inside the step. */
+int vkas_points_margin(const int64_t* py, const int64_t* px, long n, int H, int W, int64_t* margin, void* stream);
 /* prob (B,1,H,W), offset (B,2,H,W), angle (B,4,H,W), dist (B,4,H,W) fp32 NCHW; py/px (B,P) int64;
  * gt_offsets (B,P,2), gt_angles (B,P,4), gt_dists (B,P,3) fp32. */
 int vkas_precise_loss_fwd(const float* prob, const float* offset, const float* angle, const float* dist,

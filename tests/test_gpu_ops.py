@@ -376,6 +376,65 @@ def test_adaptive_avgpool(case, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16', 'f16'])
+def test_adaptive_avgpools_one_node(dtype):
+    """The PPM's four pooled branches as one autograd node (ops.AdaptiveAvgPools): outputs are those of the single-scale op and
+    the input gradient is the sum of the branches' gradients (accumulated inside the kernels), also with an unused branch."""
+    ops = ops_mod()
+    scales = (1, 2, 3, 6)
+    x = q(rnd((2, 24, 13, 10), 145), dtype)
+    xr = x.clone().requires_grad_(True)
+    refs = [torch.nn.AdaptiveAvgPool2d(s)(xr) for s in scales]
+    cots = [q(rnd(tuple(r.shape), 146 + i), dtype) for i, r in enumerate(refs)]
+    sum((r * c).sum() for r, c in zip(refs, cots)).backward()
+    xa = to_act(x, dtype).requires_grad_(True)
+    ys = ops.AdaptiveAvgPools.apply(xa, *scales)
+    for y, r in zip(ys, refs):
+        close(from_act(y, 24), r.detach(), dtype, 'avgpools fwd')
+    torch.autograd.backward(ys, [to_act(c, dtype) for c in cots])
+    close(from_act(xa.grad, 24), xr.grad, dtype, 'avgpools bwd')
+    # a branch without gradient is skipped, not read
+    xr2 = x.clone().requires_grad_(True)
+    (torch.nn.AdaptiveAvgPool2d(3)(xr2) * cots[2]).sum().backward()
+    xb = to_act(x, dtype).requires_grad_(True)
+    yb = ops.AdaptiveAvgPools.apply(xb, *scales)
+    yb[2].backward(to_act(cots[2], dtype))
+    close(from_act(xb.grad, 24), xr2.grad, dtype, 'avgpools bwd, one branch')
+
+
+def test_zero_arena_hands_out_clean_disjoint_slices():
+    """ops.zeros_f32 / zero_arena_reset (the per-step scratch of the weight-gradient images): before the first reset every
+    request is a fresh torch.zeros; after a reset requests are disjoint, zeroed slices of one buffer until it is exhausted, then
+    fresh tensors again; a reset clears what the kernels left behind and grows the buffer to what the step asked for."""
+    ops = ops_mod()
+    dev = torch.device('cuda', 0)
+    arena = ops._ZeroArena()
+    old, ops._ZERO_ARENA = ops._ZERO_ARENA, arena
+    try:
+        a = ops.zeros_f32(1000, dev, True)
+        assert arena.buf is None and float(a.abs().sum()) == 0.0
+        ops.zero_arena_reset()
+        assert arena.buf is not None and arena.buf.numel() == 1024
+        b = ops.zeros_f32(1000, dev, True)
+        assert b.data_ptr() == arena.buf.data_ptr() and float(b.abs().sum()) == 0.0
+        c = ops.zeros_f32(100, dev, True)        # does not fit any more: a tensor of its own
+        assert not (arena.buf.data_ptr() <= c.data_ptr() < arena.buf.data_ptr() + 4 * arena.buf.numel())
+        d = ops.zeros_f32(10, dev, False)        # not step scratch: never from the arena
+        assert not (arena.buf.data_ptr() <= d.data_ptr() < arena.buf.data_ptr() + 4 * arena.buf.numel())
+        b.fill_(3.0)
+        c.fill_(3.0)
+        ops.zero_arena_reset()                   # asked for 1024 + 128 floats: the buffer grows, and is clean
+        assert arena.buf.numel() == 1152 and float(arena.buf.abs().sum()) == 0.0
+        e, f = ops.zeros_f32(1000, dev, True), ops.zeros_f32(100, dev, True)
+        assert f.data_ptr() == e.data_ptr() + 4 * 1024
+        e.fill_(1.0)
+        assert float(f.abs().sum()) == 0.0
+        ops.zero_arena_reset()
+        assert float(arena.buf.abs().sum()) == 0.0
+    finally:
+        ops._ZERO_ARENA = old
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16', 'f16'])
 def test_cat_and_tonchw(dtype):
     ops = ops_mod()
     a, b = q(rnd((2, 16, 6, 5), 47), dtype), q(rnd((2, 8, 6, 5), 48), dtype)

@@ -122,6 +122,7 @@ _SIGS = {
                                     POINTER(RoughLossCfg), _P, _P, _P]),
     'vkas_rough_loss_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                     POINTER(RoughLossCfg), _P, _P, _P, _P, _P]),
+    'vkas_points_margin': (c_int, [_P, _P, c_long, c_int, c_int, _P, _P]),
     'vkas_precise_loss_fwd': (c_int, [_P] * 11 + [c_int] * 8 + [POINTER(PreciseLossCfg), _P, _P, _P]),
     'vkas_precise_loss_bwd': (c_int, [_P] * 11 + [c_int] * 8 + [POINTER(PreciseLossCfg), _P, _P, _P, _P, _P, _P, _P]),
     'vkas_elementwise_loss_fwd': (c_int, [c_int, _P, _P, _P, c_long, c_float, c_float, c_float, _P, _P, _P]),

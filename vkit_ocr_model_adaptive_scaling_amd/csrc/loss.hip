@@ -331,6 +331,34 @@ extern "C" int vkas_rough_loss_bwd(const float* mask_feat, const float* height_f
   return VKAS_OK;
 }
 
+// smallest distance of any label point to the border of the (H, W) map, negative when a point lies outside: the range check
+// the reference's advanced indexing performs on the host (loss_function/adaptive_scaling.py:235-262), as one workgroup
+__global__ __launch_bounds__(256) void points_margin_kernel(const int64_t* __restrict__ py, const int64_t* __restrict__ px,
+                                                            long n, int H, int W, int64_t* __restrict__ margin) {
+  __shared__ long long part[256];
+  long long m = 0x7fffffffffffffffLL;
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const long long y = py[i], x = px[i];
+    const long long a = y < (H - 1) - y ? y : (H - 1) - y, b = x < (W - 1) - x ? x : (W - 1) - x;
+    const long long c = a < b ? a : b;
+    m = c < m ? c : m;
+  }
+  part[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s && part[threadIdx.x + s] < part[threadIdx.x]) part[threadIdx.x] = part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) margin[0] = (int64_t)part[0];
+}
+
+extern "C" int vkas_points_margin(const int64_t* py, const int64_t* px, long n, int H, int W, int64_t* margin, void* stream) {
+  VKAS_CHECK(py && px && margin && n > 0 && H > 0 && W > 0, "vkas_points_margin: bad arguments");
+  points_margin_kernel<<<1, 256, 0, vkas_stream(stream)>>>(py, px, n, H, W, margin);
+  VKAS_LAUNCH_CHECK("points_margin");
+  return VKAS_OK;
+}
+
 extern "C" int vkas_precise_loss_fwd(const float* prob, const float* offset, const float* angle, const float* dist,
                                      const float* gt_score, const float* gt_mask, const int64_t* py, const int64_t* px,
                                      const float* gt_offsets, const float* gt_angles, const float* gt_dists, int B, int H,

@@ -148,8 +148,9 @@ class ConvNext(nn.Module):
         if keep is None or keep.device != device or keep.numel() != len(layers):
             keep = torch.tensor([1.0 - layer.prob_bypass for layer in layers], dtype=torch.float32, device=device)
             self._keep_probs = keep
-        k = keep[:, None]
-        m = (torch.rand((len(layers), batch), dtype=torch.float32, device=device) < k).to(torch.float32) / k.clamp_min(1e-12)
+            self._inv_keep = 1.0 / keep[:, None].clamp_min(1e-12)
+        # {0, 1} * (1 / keep) is bit for bit {0, 1} / keep: three launches per step instead of five
+        m = (torch.rand((len(layers), batch), dtype=torch.float32, device=device) < keep[:, None]) * self._inv_keep
         return [None if layer.prob_bypass == 0.0 else m[i] for i, layer in enumerate(layers)]
 
     def forward_act(self, x: torch.Tensor, masks: Optional[Sequence[Optional[torch.Tensor]]] = None):

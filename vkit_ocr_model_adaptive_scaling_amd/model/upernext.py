@@ -46,10 +46,8 @@ class PpmBlock(nn.Module):
         self.compute_dtype = torch.bfloat16
 
     def forward_act(self, x: torch.Tensor) -> torch.Tensor:
-        parts = []
-        for s, branch in zip(self.ppm_scales, self.ap_conv_blocks):
-            f = ops.AdaptiveAvgPool.apply(x, s)
-            parts.append(helper.conv_block(f, branch[1][1], branch[1][2]))
+        pooled = ops.AdaptiveAvgPools.apply(x, *self.ppm_scales)  # one node: its backward sums the branches' gradients
+        parts = [helper.conv_block(f, branch[1][1], branch[1][2]) for f, branch in zip(pooled, self.ap_conv_blocks)]
         cat = ops.ResizeCat.apply(BILINEAR, x, *parts)  # the pooled branches resized to x and concatenated behind it
         return helper.conv_block(cat, self.final_conv_block[0], self.final_conv_block[2], 1, 1)
 

@@ -96,6 +96,59 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(((nbytes + 3) // 4 + 4,), dtype=_FLOAT, device=device)
 
 
+class _ZeroArena:
+    """Zero-initialised fp32 scratch for the atomically accumulated weight-gradient images of one training step: the 15
+    per-layer ``torch.zeros`` of a backward pass become slices of one buffer that a single fill clears once per step
+    (``zero_arena_reset``, called by ``FlatBuffers.zero_grad``).  A slice is handed out once between two resets, so it is
+    clean when its kernel starts and may be dirty afterwards; callers ask for arena memory only for buffers that do not
+    outlive the step (their contents are unpacked / added into the flat gradient before the optimizer runs).  Without resets
+    (no flat optimizer) every request falls back to ``torch.zeros``."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+        self.off = 0      # floats handed out since the last reset
+        self.want = 0     # floats asked for since the last reset (sizes the buffer at the next one)
+        self.live = False
+
+    def take(self, n: int, device) -> Optional[torch.Tensor]:
+        n_al = -(-n // 64) * 64  # 256-byte aligned slices
+        self.want += n_al
+        if not self.live or self.buf.device != device or self.off + n_al > self.buf.numel():
+            return None
+        t = self.buf[self.off:self.off + n]
+        self.off += n_al
+        return t
+
+    def reset(self):
+        if self.want == 0 and self.off == 0:
+            return  # nothing was asked for since the last reset: the buffer (if any) is still clean
+        if self.buf is None or self.want > self.buf.numel():
+            dev = self.buf.device if self.buf is not None else torch.device('cuda', torch.cuda.current_device())
+            self.buf = None
+            self.buf = torch.zeros((self.want,), dtype=_FLOAT, device=dev)
+        else:
+            self.buf.zero_()
+        self.off, self.want, self.live = 0, 0, True
+
+
+_ZERO_ARENA = _ZeroArena()
+_NO_ZERO_ARENA = os.environ.get('VKAS_NO_ZERO_ARENA') is not None  # A/B switch
+
+
+def zero_arena_reset():
+    if not _NO_ZERO_ARENA:
+        _ZERO_ARENA.reset()
+
+
+def zeros_f32(n: int, device, step_scratch: bool) -> torch.Tensor:
+    """n zeroed floats; step_scratch: the buffer is dead before the step's optimizer update (see _ZeroArena)."""
+    if step_scratch and not _NO_ZERO_ARENA:
+        t = _ZERO_ARENA.take(n, device)
+        if t is not None:
+            return t
+    return torch.zeros((n,), dtype=_FLOAT, device=device)
+
+
 # ---------------------------------------------------------------------------------------- raw wrappers
 # Packed operands derived from parameters (GEMM weight layouts, padded vectors) are cached between the uses of one
 # parameter value: a weight is used by the forward and the backward of both passes of a step, i.e. packed once per
@@ -393,13 +446,15 @@ def deliver_small_grads(pairs):
 
 
 def conv_wgrad(x: torch.Tensor, geom: ConvGeom, dy: torch.Tensor, Np: int, nk=None, with_bias: bool = False,
-               x_gelu: bool = False, gw_into: Optional[torch.Tensor] = None, gb_into: Optional[torch.Tensor] = None):
+               x_gelu: bool = False, gw_into: Optional[torch.Tensor] = None, gb_into: Optional[torch.Tensor] = None,
+               step_scratch: bool = False):
     """Weight gradient in the packed (Np, K) layout; with_bias also returns the fused bias gradient (Np,): the two
     live in one zero-filled buffer so a single memset covers both.  x_gelu: the input operand is gelu(x).
-    gw_into / gb_into: existing fp32 buffers to ACCUMULATE into (the kernels add with atomics) instead of fresh zeros."""
+    gw_into / gb_into: existing fp32 buffers to ACCUMULATE into (the kernels add with atomics) instead of fresh zeros.
+    step_scratch: the caller consumes the result before the step ends (zeros_f32)."""
     K = geom.KH * geom.KW * geom.Cp
     n_new = (0 if gw_into is not None else Np * K) + (Np if with_bias and gb_into is None else 0)
-    buf = torch.zeros((n_new,), dtype=_FLOAT, device=x.device) if n_new else None
+    buf = zeros_f32(n_new, x.device, step_scratch) if n_new else None
     gw = gw_into if gw_into is not None else buf[:Np * K]
     gb = None
     if with_bias:
@@ -442,7 +497,11 @@ def conv_param_grads(x, geom, dy, Np: int, weight: torch.Tensor, bias: Optional[
     same_layout = KH == 1 and KW == 1 and Np == N and Cp == C  # packed (Np, K) rows are the reference rows
     gw_into = weight.grad.view(-1) if (sw is not None and same_layout) else None
     gb_into = bias.grad if (sb is not None and Np == N) else None
-    r = conv_wgrad(x, geom, dy, Np, nk=nk, with_bias=bias is not None, x_gelu=x_gelu, gw_into=gw_into, gb_into=gb_into)
+    # with flat gradient sinks nothing of the packed buffer survives the step: the weight image is unpacked into the sink and
+    # a bias gradient that is returned to autograd is added onto the sink's view in place (never adopted as .grad)
+    scratch = sw is not None and (bias is None or sb is not None)
+    r = conv_wgrad(x, geom, dy, Np, nk=nk, with_bias=bias is not None, x_gelu=x_gelu, gw_into=gw_into, gb_into=gb_into,
+                   step_scratch=scratch)
     gwp, gbp = r if bias is not None else (r, None)
     if gw_into is not None:
         gw = None
@@ -807,6 +866,26 @@ def pack_head_weights(ws: Sequence[torch.Tensor], nps: Sequence[int], Cp: int, m
     return _cached_pack_multi(list(ws), key, build)
 
 
+def pack_head_bias(bs: Sequence[torch.Tensor], cs: Sequence[int], nps: Sequence[int]) -> torch.Tensor:
+    """The heads' conv biases side by side, each padded to its np columns (fp32): the bias operand of the fused head GEMM.
+    Rebuilt by vkas_pack_many with the other parameter images after an optimizer step (a bias is a 1 x 1 x 1 'weight')."""
+    Nt = sum(nps)
+    key = ('head_bias', tuple(nps))
+
+    def build():
+        t = torch.empty((Nt,), dtype=_FLOAT, device=bs[0].device)
+        off, descs = 0, []
+        for b, c, np_ in zip(bs, cs, nps):
+            src = b.detach().contiguous()
+            check(lib.vkas_pad_vector(_p(src), ctypes.c_void_p(t.data_ptr() + 4 * off), c, np_, _stream()), 'pad_vector')
+            descs.append(_lib.PackDesc(src.data_ptr(), t.data_ptr(), np_, 0, c, 1, 1, 1, np_, 1, 0, off, Nt, _dtc(_FLOAT)))
+            off += np_
+        if all(b.is_leaf and b.requires_grad and b.is_contiguous() for b in bs):
+            _plan_pack((tuple(id(b) for b in bs), key), descs, list(bs))
+        return t
+    return _cached_pack_multi(list(bs), key, build)
+
+
 class HeadsFused(Function):
     """All heads of a pass (model/upernext.py:215-223 or model/fpn.py:165-183, shared upsampled input) as ONE implicit
     GEMM whose epilogue applies each head's LayerNorm -> GELU -> Linear(C -> out_channels) per pixel: forward writes
@@ -856,15 +935,8 @@ class HeadsFused(Function):
                                                 _p(t[h]), _stream()), 'pack_head_params')
             return t
 
-        def build_bias():
-            t = torch.zeros((Nt,), dtype=_FLOAT, device=dev)
-            off = 0
-            for b, c, np_ in zip(bs, cs, nps):
-                t[off:off + c].copy_(b.detach())
-                off += np_
-            return t
         hp = _cached_pack_multi(list(gammas) + list(betas) + list(wps) + list(bps), ('head_params', pw), build_hp)
-        b_cat = _cached_pack_multi(list(bs), ('head_bias', tuple(nps)), build_bias)
+        b_cat = pack_head_bias(bs, cs, nps)
         # z and the row statistics only serve the backward pass: an inference (no-grad) call does not write them
         # (the wide-head path needs z as the tail kernel's input either way)
         z = new_act(B, H, W, Nt, x) if (keep or not in_epilogue) else None
@@ -904,7 +976,9 @@ class HeadsFused(Function):
         PS = 6 * pw + 8
         offs = [sum(nps[:h]) for h in range(n_heads + 1)]
         dparams = torch.empty((n_heads, PS), dtype=_FLOAT, device=dev)
-        gbuf = torch.zeros((Nt * K + Nt,), dtype=_FLOAT, device=dev)  # packed weight gradient | bias gradient, one memset
+        # packed weight gradient | bias gradient; with flat gradient sinks both are unpacked / added into the sinks below
+        flat_sinks = all(grad_sink(p) is not None for p in list(ws) + list(bs))
+        gbuf = zeros_f32(Nt * K + Nt, dev, flat_sinks)
         gwp, gbp = gbuf[:Nt * K], gbuf[Nt * K:]
         dps = []
         for h in range(n_heads):
@@ -982,7 +1056,7 @@ class HeadsFused(Function):
                 Wf = pack_head_weights(ws, nps, Cp, 0, x.dtype)[offs[s0] * K:offs[s1] * K].view(1, 1, Ns, K)
                 dzt = dzs.view(Mp, Ns).t().contiguous().view(1, 1, Ns, Mp)
                 g3 = _geom(1, 1, Ns, 1, Ns, K, K, 1, 1, 1, 0)
-                D = conv_wgrad(Wf, g3, dzt, Mp, nk=(B * P, C * 9))
+                D = conv_wgrad(Wf, g3, dzt, Mp, nk=(B * P, C * 9), step_scratch=True)
                 check(lib.vkas_points_scatter3x3(_p(D), _p(pix), _p(pmap), Mp, B, H, W, Cp, _p(dx), act_ld(dx), _dt(x),
                                                  _stream()), 'points_scatter3x3')
         gws, gbs = [], []
@@ -1086,15 +1160,8 @@ class HeadsAtPoints(Function):
                                                 _p(t[h]), _stream()), 'pack_head_params')
             return t
 
-        def build_bias():
-            t = torch.zeros((Ns,), dtype=_FLOAT, device=dev)
-            off = 0
-            for b, c, np_ in zip(bs, cs, nps):
-                t[off:off + c].copy_(b.detach())
-                off += np_
-            return t
         hp = _cached_pack_multi(list(gammas) + list(betas) + list(wps) + list(bps), ('head_params', pw), build_hp)
-        b_cat = _cached_pack_multi(list(bs), ('head_bias', tuple(nps)), build_bias)
+        b_cat = pack_head_bias(bs, cs, nps)
         Wf = pack_head_weights(ws, nps, Cp, 0, x.dtype)
         zs = new_act(1, 1, Mp, Ns, x)
         g1 = _geom(1, 1, Mp, 1, Mp, K, K, 1, 1, 1, 0)
@@ -1151,13 +1218,14 @@ class HeadsAtPoints(Function):
         check(lib.vkas_head_tail_bwd(_p(zs), Ns, ctypes.byref(head), ptrs, _p(dzs), Ns, _p(dparams), _p(ws_buf), nbytes, Mp,
                                      _dtc(dtype), _stream()), 'head_tail_bwd')
         g1 = _geom(1, 1, Mp, 1, Mp, K, K, 1, 1, 1, 0)
-        gwp, gbp = conv_wgrad(xs, g1, dzs, Ns, nk=(sum(cs), C * 9), with_bias=True)
+        gwp, gbp = conv_wgrad(xs, g1, dzs, Ns, nk=(sum(cs), C * 9), with_bias=True,
+                              step_scratch=all(grad_sink(p) is not None for p in list(ws) + list(bs)))
         dx = None
         if ctx.needs_input_grad[0]:
             Wf = pack_head_weights(ws, nps, Cp, 0, dtype).view(1, 1, Ns, K)
             dzt = dzs.view(Mp, Ns).t().contiguous().view(1, 1, Ns, Mp)
             g3 = _geom(1, 1, Ns, 1, Ns, K, K, 1, 1, 1, 0)
-            D = conv_wgrad(Wf, g3, dzt, Mp, nk=(B * P, C * 9))
+            D = conv_wgrad(Wf, g3, dzt, Mp, nk=(B * P, C * 9), step_scratch=True)
             dx = torch.zeros((B, H, W, Cp), dtype=dtype, device=dev)
             check(lib.vkas_points_scatter3x3(_p(D), _p(pix), _p(pmap), Mp, B, H, W, Cp, _p(dx), Cp, _dtc(dtype), _stream()),
                   'points_scatter3x3')
@@ -1455,6 +1523,42 @@ class AdaptiveAvgPool(Function):
         return dx, None
 
 
+class AdaptiveAvgPools(Function):
+    """[nn.AdaptiveAvgPool2d(s)(x) for s in scales] (the PPM's pooled branches, model/upernext.py:58-66) as one autograd node:
+    backward adds the branches' gradients inside the pooling kernels (accumulate flag) instead of leaving len(scales) - 1 adds
+    of full-size tensors to the autograd engine."""
+
+    @staticmethod
+    def forward(ctx, x, *scales: int):
+        _require_cuda(x)
+        x = as_act(x)
+        B, H, W, Cp = x.shape
+        ys = []
+        for s in scales:
+            y = new_act(B, s, s, Cp, x)
+            check(lib.vkas_adaptive_avgpool_fwd(_p(x), act_ld(x), _p(y), Cp, B, H, W, s, Cp, _dt(x), _stream()),
+                  'adaptive_avgpool_fwd')
+            ys.append(y)
+        ctx.cfg = (B, H, W, Cp, tuple(scales), x.dtype, x.device)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        B, H, W, Cp, scales, dtype, dev = ctx.cfg
+        dx = torch.empty((B, H, W, Cp), dtype=dtype, device=dev)
+        first = True
+        for s, dy in zip(scales, dys):
+            if dy is None:
+                continue
+            dy = as_act(dy)
+            check(lib.vkas_adaptive_avgpool_bwd(_p(dy), act_ld(dy), _p(dx), Cp, B, H, W, s, Cp, 0 if first else 1, _dt(dy),
+                                                _stream()), 'adaptive_avgpool_bwd')
+            first = False
+        if first:
+            dx.zero_()
+        return (dx,) + (None,) * len(scales)
+
+
 class Cat(Function):
     """torch.cat along channels (model/upernext.py:82,197, model/fpn.py:144): each part is written into its channel
     slice of one NHWC buffer; backward hands out slices (views) of the incoming gradient."""
@@ -1691,7 +1795,8 @@ class PreciseLoss(Function):
             # device and its verdict travels to pinned host memory asynchronously: reading it here would stall the
             # launch pipeline once per step, so it is examined at the NEXT loss call / check_deferred() (one step late).
             check_deferred()
-            lim = torch.stack((py, (H - 1) - py, px, (W - 1) - px)).amin().reshape(1)
+            lim = torch.empty((1,), dtype=torch.int64, device=py.device)
+            check(lib.vkas_points_margin(_p(py), _p(px), B * P, H, W, _p(lim), _stream()), 'points_margin')
             _defer_check(lim, f'PreciseLoss: label points outside the {H}x{W} map')
         sums = torch.empty((8,), dtype=torch.float64, device=prob.device)
         loss = torch.empty((), dtype=_FLOAT, device=prob.device)

@@ -131,6 +131,7 @@ class TwoPassStep:
         # opt-in, NOT the reference's module API: the regression heads' forward at the label points only (the precise loss
         # reads nothing else of them); same losses and gradients, see ops.HeadsAtPoints
         self.label_point_forward = label_point_forward
+        self._one: Optional[torch.Tensor] = None
 
     def _rough_loss(self, outs, b, scale):
         mask, height = outs
@@ -156,7 +157,11 @@ class TwoPassStep:
             precise_loss = self._precise_loss(precise_out, precise_batch, scale)
             if r is not None:
                 r.arm(['rough', 'precise'] + self._backbone_buckets)
-            (rough_loss + precise_loss).backward()
+            # d(rough_loss + precise_loss) without building the sum: both roots seeded with a cached 1
+            one = self._one
+            if one is None or one.device != rough_loss.device or one.dtype != rough_loss.dtype or one.shape != rough_loss.shape:
+                one = self._one = torch.ones_like(rough_loss)
+            torch.autograd.backward((rough_loss, precise_loss), (one, one))
         else:
             rough_loss = self._rough_loss(self.model.forward_rough(rough_batch['image']), rough_batch, scale)
             if r is not None:

@@ -114,6 +114,9 @@ class FlatBuffers:
 
     def zero_grad(self):
         self.flat_grad.zero_()
+        if self.flat_grad.is_cuda:
+            from .. import ops
+            ops.zero_arena_reset()  # the step's weight-gradient scratch is dead by now: one fill re-arms it
         self.touched = bytearray(len(self.params))
         for n, p in zip(self.names, self.params):  # re-attach views if someone set .grad to None
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * self.offsets[n][0]:
