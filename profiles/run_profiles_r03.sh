@@ -10,7 +10,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-per-pass > $O/write.log 2>&1
 mkdir -p $R/gpurun_out/${L}
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${L}/${L}_kernel_stats.csv
-tail -3 $O/stats.log > $R/gpurun_out/${L}/${L}_stats.log
+grep -e '"metric"' -e '^\[bench\]' $O/stats.log > $R/gpurun_out/${L}/${L}_stats.log
 python3 $R/profiles/parse_pmc.py $(find $O/fetch -name "*counter_collection.csv" | head -1) $(find $O/write -name "*counter_collection.csv" | head -1) \
   $R/gpurun_out/${L}/pmc_traffic.json "profiles/${L} rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --steps 1 --warmup 0 --no-per-pass (commit ${2:-HEAD})" \
   > $R/gpurun_out/${L}/${L}_pmc_traffic.txt
