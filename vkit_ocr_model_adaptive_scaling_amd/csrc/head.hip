@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
   const float invC = 1.f / (float)C;
 
   // in-flight loads of one row pair
-  float xr[R][8], mean[R], rstd[R];
+  Raw8<T> xr[R];  // as loaded: converted when the pair is processed, not when it is requested
+  float mean[R], rstd[R];
   float4 dp[R];
   auto fetch = [&](long m0) {
 #pragma unroll
@@ -100,9 +101,8 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
       mean[r] = ok ? hstats[2 * m] : 0.f;
       rstd[r] = ok ? hstats[2 * m + 1] : 0.f;
       dp[r] = ok ? *reinterpret_cast<const float4*>(hdproj + m * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int c = 0; c < 8; ++c) xr[r][c] = 0.f;
-      if (ok && vok) load8(z + m * ldz + n0 + gl * 8, xr[r]);
+      xr[r].zero();
+      if (ok && vok) xr[r].load(z + m * ldz + n0 + gl * 8);
     }
   };
   fetch(mbeg);
@@ -114,8 +114,7 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
       mu[r] = mean[r];
       rs[r] = rstd[r];
       d4v[r] = dp[r];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) x[r][c] = xr[r][c];
+      xr[r].unpack(x[r]);
     }
     if (m0 + (long)R * rpi < mend) fetch(m0 + (long)R * rpi);  // next pair: in flight behind this pair's arithmetic
     float gm[8], bt[8];

@@ -32,6 +32,22 @@ static inline int pick_group(int nvec) {
   return g;
 }
 
+#ifndef LN_BWD_R1
+#define LN_BWD_R1 2
+#endif
+#ifndef LN_FWD_R1
+#define LN_FWD_R1 4
+#endif
+#ifndef LN_BLOCKS
+#define LN_BLOCKS 1024
+#endif
+#ifndef SR_UNROLL
+#define SR_UNROLL 1
+#endif
+#ifndef LN_BWD_PREFETCH
+#define LN_BWD_PREFETCH 0
+#endif
+
 // R rows per lane group are in flight together (all loads issued before the first reduction): a single 16-byte
 // load per lane leaves the memory system mostly idle, 4 of them per lane reach the HBM-bound regime.
 template <typename T, int MAXV, int R>
@@ -45,6 +61,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   const int rpi = 256 / G;
   const long mb = ((long)blockIdx.x * R) * rpi + threadIdx.x / G;
   float v[R][MAXV][8];
+  Raw8<T> raw[R][MAXV];  // every load of the R rows is issued before the first conversion
   float s[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -53,11 +70,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int vi = gl + i * G;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) v[r][i][c] = 0.f;
-      if (m < M && vi < nvec) load8(x + m * ldx + vi * 8, v[r][i]);
+      raw[r][i].zero();
+      if (m < M && vi < nvec) raw[r][i].load(x + m * ldx + vi * 8);
     }
   }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) raw[r][i].unpack(v[r][i]);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
 #pragma unroll
@@ -151,26 +171,45 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       load8(beta + vi * 8, bt[i]);
     }
   }
-  for (long m0 = mbeg; m0 < mend; m0 += (long)R * rpi) {
-    float xh[R][MAXV][8], g[R][MAXV][8];  // first hold the raw x / dy, then x-hat / effective gradient
-    float mean[R], rstd[R];
+  // LN_BWD_PREFETCH: the rows of the NEXT iteration are requested (as raw 16-byte pieces) before the current ones are
+  // processed, so a lane keeps twice the bytes in flight
+  Raw8<T> nx[R][MAXV], nd[R][MAXV];
+  float nmean[R], nrstd[R];
+  auto fetch = [&](long m0) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const long m = m0 + (long)r * rpi + rl;
       const bool ok = m < mend;
-      mean[r] = ok ? stats[2 * m] : 0.f;
-      rstd[r] = ok ? stats[2 * m + 1] : 0.f;
+      nmean[r] = ok ? stats[2 * m] : 0.f;
+      nrstd[r] = ok ? stats[2 * m + 1] : 0.f;
 #pragma unroll
       for (int i = 0; i < MAXV; ++i) {
         const int vi = gl + i * G;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { xh[r][i][c] = 0.f; g[r][i][c] = 0.f; }
+        nx[r][i].zero();
+        nd[r][i].zero();
         if (ok && vi < nvec) {
-          load8(x + m * ldx + vi * 8, xh[r][i]);
-          load8(dy + m * lddy + vi * 8, g[r][i]);
+          nx[r][i].load(x + m * ldx + vi * 8);
+          nd[r][i].load(dy + m * lddy + vi * 8);
         }
       }
     }
+  };
+  if (LN_BWD_PREFETCH) fetch(mbeg);
+  for (long m0 = mbeg; m0 < mend; m0 += (long)R * rpi) {
+    float xh[R][MAXV][8], g[R][MAXV][8];  // first hold the raw x / dy, then x-hat / effective gradient
+    float mean[R], rstd[R];
+    if (!LN_BWD_PREFETCH) fetch(m0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      mean[r] = nmean[r];
+      rstd[r] = nrstd[r];
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        nx[r][i].unpack(xh[r][i]);
+        nd[r][i].unpack(g[r][i]);
+      }
+    }
+    if (LN_BWD_PREFETCH && m0 + (long)R * rpi < mend) fetch(m0 + (long)R * rpi);
     float s1[R], s2[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -263,19 +302,38 @@ __global__ __launch_bounds__(256) void scale_res_bwd_kernel(const T* __restrict_
   const long mbeg = (long)blockIdx.x * rows_per_block;
   const long mend = mbeg + rows_per_block < M ? mbeg + rows_per_block : M;
   if (rl < lanes_r) {
-    for (long m = mbeg + rl; m < mend; m += lanes_r) {
-      float d[8], zz[8], o[8];
-      load8(dout + m * lddo + v * 8, d);
-      load8(z + m * ldz + v * 8, zz);
-      const float rs = rowscale ? rowscale[m / rows_per_image] : 1.f;
+    // SR_UNROLL rows per lane and iteration, all their loads issued before the first use
+    for (long m0 = mbeg + rl; m0 < mend; m0 += (long)SR_UNROLL * lanes_r) {
+      Raw8<T> rd[SR_UNROLL], rz[SR_UNROLL];
+      float rs[SR_UNROLL];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float t = d[c] * rs;
-        a1[c] += t * zz[c];
-        o[c] = t * cs[c];
-        a2[c] += o[c];
+      for (int u = 0; u < SR_UNROLL; ++u) {
+        const long m = m0 + (long)u * lanes_r;
+        rd[u].zero();
+        rz[u].zero();
+        rs[u] = 0.f;
+        if (m < mend) {
+          rd[u].load(dout + m * lddo + v * 8);
+          rz[u].load(z + m * ldz + v * 8);
+          rs[u] = rowscale ? rowscale[m / rows_per_image] : 1.f;
+        }
       }
-      store8(dz + m * lddz + v * 8, o);
+#pragma unroll
+      for (int u = 0; u < SR_UNROLL; ++u) {
+        const long m = m0 + (long)u * lanes_r;
+        if (m >= mend) break;
+        float d[8], zz[8], o[8];
+        rd[u].unpack(d);
+        rz[u].unpack(zz);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float t = d[c] * rs[u];
+          a1[c] += t * zz[c];
+          o[c] = t * cs[c];
+          a2[c] += o[c];
+        }
+        store8(dz + m * lddz + v * 8, o);
+      }
     }
   }
   __shared__ float red[256 * 8];
@@ -299,7 +357,7 @@ __global__ __launch_bounds__(256) void scale_res_bwd_kernel(const T* __restrict_
 // about 1024 workgroups per launch (4 per CU); never fewer than 32 rows per workgroup so that small feature maps
 // (stage 2/3: 8K-32K pixels) still spread over the whole chip
 static inline long rows_per_block_for(long M, long quantum) {
-  long r = vkas_cdiv(M > 0 ? M : 1, 1024);
+  long r = vkas_cdiv(M > 0 ? M : 1, LN_BLOCKS);
   if (r < 32) r = 32;
   return vkas_cdiv(r, quantum) * quantum;
 }
@@ -319,7 +377,7 @@ extern "C" int vkas_layernorm_fwd(const void* x, long ldx, const float* gamma, c
   VKAS_DISPATCH_DTYPE(dtype, "vkas_layernorm_fwd", {
     hipStream_t st = vkas_stream(stream);
     if (vpl == 1)
-      layernorm_fwd_kernel<T, 1, 4><<<(unsigned)vkas_cdiv(M, rows * 4), 256, 0, st>>>((const T*)x, ldx, gamma, beta, (T*)y, ldy, stats, M, C, Cp, G, act_gelu);
+      layernorm_fwd_kernel<T, 1, LN_FWD_R1><<<(unsigned)vkas_cdiv(M, rows * LN_FWD_R1), 256, 0, st>>>((const T*)x, ldx, gamma, beta, (T*)y, ldy, stats, M, C, Cp, G, act_gelu);
     else if (vpl == 2)
       layernorm_fwd_kernel<T, 2, 2><<<(unsigned)vkas_cdiv(M, rows * 2), 256, 0, st>>>((const T*)x, ldx, gamma, beta, (T*)y, ldy, stats, M, C, Cp, G, act_gelu);
     else
@@ -331,14 +389,14 @@ extern "C" int vkas_layernorm_fwd(const void* x, long ldx, const float* gamma, c
 
 extern "C" size_t vkas_layernorm_bwd_ws_bytes(long M, int Cp) {
   const int G = pick_group(Cp >> 3);
-  const long rpb = rows_per_block_for(M, 2 * (256 / G));
+  const long rpb = rows_per_block_for(M, LN_BWD_R1 * (256 / G));
   return (size_t)vkas_cdiv(M > 0 ? M : 1, rpb) * 2 * (size_t)Cp * sizeof(float);
 }
 
 extern "C" long vkas_layernorm_bwd_parts(long M, int Cp) {  // partial rows (2 Cp floats each: dgamma | dbeta) left in ws
   if (M <= 0) return 0;
   const int G = pick_group(Cp >> 3);
-  return vkas_cdiv(M, rows_per_block_for(M, 2 * (256 / G)));
+  return vkas_cdiv(M, rows_per_block_for(M, LN_BWD_R1 * (256 / G)));
 }
 
 extern "C" int vkas_layernorm_bwd(const void* x, long ldx, const float* gamma, const float* beta, const float* stats,
@@ -361,12 +419,12 @@ extern "C" int vkas_layernorm_bwd(const void* x, long ldx, const float* gamma, c
     return VKAS_OK;
   }
   const int G = pick_group(Cp >> 3);
-  const long rpb = rows_per_block_for(M, 2 * (256 / G));
+  const long rpb = rows_per_block_for(M, LN_BWD_R1 * (256 / G));
   const long P = vkas_cdiv(M, rpb);
   const int vpl = (int)vkas_cdiv(Cp >> 3, G);
   VKAS_DISPATCH_DTYPE(dtype, "vkas_layernorm_bwd", {
     if (vpl == 1)
-      layernorm_bwd_kernel<T, 1, 2><<<(unsigned)P, 256, 0, st>>>((const T*)x, ldx, gamma, beta, stats, (const T*)dy, lddy,
+      layernorm_bwd_kernel<T, 1, LN_BWD_R1><<<(unsigned)P, 256, 0, st>>>((const T*)x, ldx, gamma, beta, stats, (const T*)dy, lddy,
                                                               (T*)dx, lddx, ws, M, C, Cp, G, act_gelu, rpb);
     else if (vpl == 2)
       layernorm_bwd_kernel<T, 2, 1><<<(unsigned)P, 256, 0, st>>>((const T*)x, ldx, gamma, beta, stats, (const T*)dy, lddy,

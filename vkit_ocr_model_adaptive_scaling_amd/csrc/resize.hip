@@ -256,10 +256,17 @@ __global__ __launch_bounds__(256) void resize2x_fwd_kernel(const T* __restrict__
   const T* xb = x + (long)b * Hin * Win * ldx + v * 8;
   float n[3][3][8];
   const int ys[3] = {im, i, ip}, xs[3] = {jm, j, jp};
+  {
+    Raw8<T> raw[3][3];  // all nine requests first, conversions afterwards
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) load8(xb + ((long)ys[r] * Win + xs[c]) * ldx, n[r][c]);
+      for (int c = 0; c < 3; ++c) raw[r][c].load(xb + ((long)ys[r] * Win + xs[c]) * ldx);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) raw[r][c].unpack(n[r][c]);
+  }
   // destination 2i + a reads (row A, row B, weight of B): a = 0: (i-1, i, 0.75), at i = 0 the generic index function gives
   // (0, 1, 0); a = 1: (i, i+1 clamped, 0.25).  Same along x.
   const float wy[2] = {i == 0 ? 0.f : 0.75f, 0.25f}, wx[2] = {j == 0 ? 0.f : 0.75f, 0.25f};
@@ -320,15 +327,29 @@ __global__ __launch_bounds__(256) void resize2x_bwd_kernel(const T* __restrict__
   }
   const T* db = dy + ((long)b * Hout * Wout) * lddy + v * 8;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // All sixteen destinations are requested before the first one is used (a destination outside the map - zero weight - reads
+  // its clamped neighbour instead of branching around the load); the sums below still skip zero weights, so they are those of
+  // the generic kernel term for term.
+  Raw8<T> raw[4][4];
 #pragma unroll
   for (int jy = 0; jy < 4; ++jy) {
-    if (wy4[jy] == 0.f) continue;
+    int oy = 2 * iy - 1 + jy;
+    oy = oy < 0 ? 0 : (oy >= Hout ? Hout - 1 : oy);
 #pragma unroll
     for (int jx = 0; jx < 4; ++jx) {
-      if (wx4[jx] == 0.f) continue;
-      float t[8];
-      load8(db + ((long)(2 * iy - 1 + jy) * Wout + 2 * ix - 1 + jx) * lddy, t);
+      int ox = 2 * ix - 1 + jx;
+      ox = ox < 0 ? 0 : (ox >= Wout ? Wout - 1 : ox);
+      raw[jy][jx].load(db + ((long)oy * Wout + ox) * lddy);
+    }
+  }
+#pragma unroll
+  for (int jy = 0; jy < 4; ++jy) {
+#pragma unroll
+    for (int jx = 0; jx < 4; ++jx) {
       const float wgt = wy4[jy] * wx4[jx];
+      if (wgt == 0.f) continue;
+      float t[8];
+      raw[jy][jx].unpack(t);
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] = fmaf(wgt, t[k], acc[k]);
     }

@@ -97,6 +97,29 @@ __device__ __forceinline__ void store8(f16_t* p, const float* v) {
   for (int i = 0; i < 8; ++i) a[i] = (f16_t)v[i];
   *reinterpret_cast<f16x8*>(p) = a;
 }
+// 8 consecutive elements as loaded (16 bytes of 16-bit values, 32 bytes of floats), converted to 8 floats later: a kernel
+// that issues all its loads in this form first keeps them in flight together (load8 converts at once, which makes the
+// compiler wait for each load where it stands)
+template <typename T> struct Raw8;
+template <> struct Raw8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+  __device__ __forceinline__ void zero() { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+  __device__ __forceinline__ void unpack(float* v) const { v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; }
+};
+template <> struct Raw8<bf16_t> {
+  bf16x8 a;
+  __device__ __forceinline__ void load(const bf16_t* p) { a = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ void zero() { for (int i = 0; i < 8; ++i) a[i] = (bf16_t)0.f; }
+  __device__ __forceinline__ void unpack(float* v) const { for (int i = 0; i < 8; ++i) v[i] = (float)a[i]; }
+};
+template <> struct Raw8<f16_t> {
+  f16x8 a;
+  __device__ __forceinline__ void load(const f16_t* p) { a = *reinterpret_cast<const f16x8*>(p); }
+  __device__ __forceinline__ void zero() { for (int i = 0; i < 8; ++i) a[i] = (f16_t)0.f; }
+  __device__ __forceinline__ void unpack(float* v) const { for (int i = 0; i < 8; ++i) v[i] = (float)a[i]; }
+};
+
 __device__ __forceinline__ void load4(const float* p, float* v) {
   const float4 a = *reinterpret_cast<const float4*>(p);
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
