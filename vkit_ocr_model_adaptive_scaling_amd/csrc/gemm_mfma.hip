@@ -212,18 +212,50 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[TM][TN], float* stage, 
         store4(reinterpret_cast<elem_t*>(st + row * PB) + cl, v);
       }
     }
+    // epilogues that read a second operand (the residual, the pre-activation of the GELU backward): all of this lane's row
+    // pieces are requested here - the accumulators are dead, their registers free - so the requests are in flight together
+    // behind the barrier instead of costing one global-load latency per pair of pieces
+    constexpr int NIT = (BM * VPR + NTHR - 1) / NTHR;
+    const bool pre = e.aux != nullptr && (e.mode == VKAS_EPI_SCALE_RES || e.mode == VKAS_EPI_DGELU || e.mode == VKAS_EPI_ADD);
+    Raw8<elem_t> auxr[NIT];
+    if (pre) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int t = tid + it * NTHR;
+        const int row = t / VPR, c8 = t - row * VPR;
+        const long m = m0 + row;
+        const int n = n0 + c8 * 8;
+        auxr[it].zero();
+        if (t < BM * VPR && m < M && n < n_end) auxr[it].load(reinterpret_cast<const elem_t*>(e.aux) + m * e.ldaux + n);
+      }
+    }
     __syncthreads();
     vkas_epilogue e2 = e;
     e2.bias = nullptr;  // already added
+    if (pre) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int t = tid + it * NTHR;
+        const int row = t / VPR, c8 = t - row * VPR;
+        const long m = m0 + row;
+        const int n = n0 + c8 * 8;
+        if (t < BM * VPR && m < M && n < n_end) {
+          float v[8];
+          load8(reinterpret_cast<const elem_t*>(st + row * PB) + c8 * 8, v);
+          epi_store8<elem_t>(e2, m, n, v, &auxr[it]);
+        }
+      }
+    } else {
 #pragma unroll 2
-    for (int t = tid; t < BM * VPR; t += NTHR) {
-      const int row = t / VPR, c8 = t - row * VPR;
-      const long m = m0 + row;
-      const int n = n0 + c8 * 8;
-      if (m < M && n < n_end) {
-        float v[8];
-        load8(reinterpret_cast<const elem_t*>(st + row * PB) + c8 * 8, v);
-        epi_store8<elem_t>(e2, m, n, v);
+      for (int t = tid; t < BM * VPR; t += NTHR) {
+        const int row = t / VPR, c8 = t - row * VPR;
+        const long m = m0 + row;
+        const int n = n0 + c8 * 8;
+        if (m < M && n < n_end) {
+          float v[8];
+          load8(reinterpret_cast<const elem_t*>(st + row * PB) + c8 * 8, v);
+          epi_store8<elem_t>(e2, m, n, v);
+        }
       }
     }
   } else {

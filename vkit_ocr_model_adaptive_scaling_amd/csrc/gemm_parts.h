@@ -101,8 +101,10 @@ __device__ __forceinline__ void epi_store4(const vkas_epilogue& e, long m, int n
 
 // 8 consecutive output columns n..n+7 of row m (n % 8 == 0): the coalesced form used by the MFMA kernels, whose
 // accumulators are first transposed through LDS so that a lane owns a 16-byte piece of an output row.
+// aux_pre: the 8 values of e.aux at (m, n) when the caller has requested them ahead of time (nt_epilogue issues all of a
+// lane's requests before the tile is staged, so they are in flight together instead of one latency per row piece)
 template <typename T>
-__device__ __forceinline__ void epi_store8(const vkas_epilogue& e, long m, int n, float* v) {
+__device__ __forceinline__ void epi_store8(const vkas_epilogue& e, long m, int n, float* v, const Raw8<T>* aux_pre = nullptr) {
   if (e.bias) {
     float b[8];
     load8(e.bias + n, b);
@@ -135,7 +137,8 @@ __device__ __forceinline__ void epi_store8(const vkas_epilogue& e, long m, int n
     case VKAS_EPI_SCALE_RES: {
       if (e.out2) store8(reinterpret_cast<T*>(e.out2) + m * e.ldo2 + n, v);
       float r[8], cs[8];
-      load8(reinterpret_cast<const T*>(e.aux) + m * e.ldaux + n, r);
+      if (aux_pre) aux_pre->unpack(r);
+      else load8(reinterpret_cast<const T*>(e.aux) + m * e.ldaux + n, r);
       load8(e.colscale + n, cs);
       const float rs = e.rowscale ? e.rowscale[m / e.rows_per_image] : 1.0f;
 #pragma unroll
@@ -145,7 +148,8 @@ __device__ __forceinline__ void epi_store8(const vkas_epilogue& e, long m, int n
     }
     case VKAS_EPI_DGELU: {
       float h[8];
-      load8(reinterpret_cast<const T*>(e.aux) + m * e.ldaux + n, h);
+      if (aux_pre) aux_pre->unpack(h);
+      else load8(reinterpret_cast<const T*>(e.aux) + m * e.ldaux + n, h);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] *= dgelu_t<T>(h[i]);
       store8(out + m * e.ldo + n, v);
@@ -153,7 +157,8 @@ __device__ __forceinline__ void epi_store8(const vkas_epilogue& e, long m, int n
     }
     case VKAS_EPI_ADD: {
       float r[8];
-      load8(reinterpret_cast<const T*>(e.aux) + m * e.ldaux + n, r);
+      if (aux_pre) aux_pre->unpack(r);
+      else load8(reinterpret_cast<const T*>(e.aux) + m * e.ldaux + n, r);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += r[i];
       store8(out + m * e.ldo + n, v);

@@ -377,6 +377,42 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
     img = (int)(m / p.rows_per_image);
     rim = (int)(m - (long)img * p.rows_per_image);
   }
+  // Forward, C <= 256: at most 16 row pieces per lane.  Their residual rows are requested here, all at once (the accumulators
+  // are dead: registers are free), instead of one global-load latency per piece inside the loop below.
+  constexpr int NPRE = (MODE == MODE_FWD && KS <= 8) ? 16 : 1;
+  Raw8<T> xres[NPRE];
+  if constexpr (NPRE > 1) {
+#pragma unroll
+    for (int it = 0; it < NPRE; ++it) {
+      const int r = rsub + it * RPI;
+      const long mm = row0 + r;
+      xres[it].zero();
+      if (rsub < RPI && r < ROWS && mm < p.M) xres[it].load(reinterpret_cast<const T*>(p.res) + mm * p.ldres + piece * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NPRE; ++it) {
+      const int r = rsub + it * RPI;
+      if (rsub < RPI && r < ROWS) {
+        if (m < p.M) {
+          const v8 zq = *reinterpret_cast<const v8*>(ep + r * PE + piece * 8);
+          if (p.z) *reinterpret_cast<v8*>(reinterpret_cast<T*>(p.z) + m * p.ldz + piece * 8) = zq;
+          const float rs = p.rowscale ? p.rowscale[img] : 1.0f;
+          float xr[8];
+          xres[it].unpack(xr);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) xr[q] += rs * cs[q] * (float)zq[q];
+          store8(reinterpret_cast<T*>(p.out) + m * p.ldo + piece * 8, xr);
+        }
+        m += RPI;
+        rim += RPI;
+        while (rim >= p.rows_per_image) {
+          rim -= p.rows_per_image;
+          ++img;
+        }
+      }
+    }
+    return;
+  }
   if (rsub < RPI) {
     for (int r = rsub; r < ROWS; r += RPI) {
       if (m < p.M) {
