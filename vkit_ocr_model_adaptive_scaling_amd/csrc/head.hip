@@ -12,6 +12,9 @@ namespace {
 // G = lanes per pixel row, one 8-channel vector each: 32 for heads up to 256 (padded) channels - ConvNeXt-T / S: 192-194 -,
 // 64 up to 512 (Base: 256-258, Large: 384+)
 constexpr int R = 2;    // rows in flight per lane group
+#ifndef HT_R1
+#define HT_R1 3
+#endif
 
 __global__ void pack_head_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                         const float* __restrict__ wproj, const float* __restrict__ bproj, int C, int oc,
@@ -50,6 +53,9 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
                                                             T* __restrict__ dz, long lddz, float* __restrict__ partial,
                                                             long M, long rows_per_block) {
   static_assert(NH == 1 || NH == 2 || NH == 4, "lane groups per row");
+  // rows in flight per lane group: the 1-channel heads (the dense launches of a train step) leave the registers for four -
+  // at two waves per SIMD the kernel is bound by the bytes it keeps in flight, not by its arithmetic alone
+  constexpr int RR = OCM == 1 ? HT_R1 : R;
   constexpr int rpi = 256 / G / NH;  // rows per sub-iteration
   constexpr int VEC = 16 / sizeof(T);
   typedef uint4 raw_t;               // 16 bytes of z: 8 bf16 (one per lane and row) / first half of 8 fp32
@@ -90,12 +96,12 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
   const float invC = 1.f / (float)C;
 
   // in-flight loads of one row pair
-  Raw8<T> xr[R];  // as loaded: converted when the pair is processed, not when it is requested
-  float mean[R], rstd[R];
-  float4 dp[R];
+  Raw8<T> xr[RR];  // as loaded: converted when the pair is processed, not when it is requested
+  float mean[RR], rstd[RR];
+  float4 dp[RR];
   auto fetch = [&](long m0) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < RR; ++r) {
       const long m = m0 + (long)r * rpi + rl;
       const bool ok = hok && m < mend;
       mean[r] = ok ? hstats[2 * m] : 0.f;
@@ -106,17 +112,17 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
     }
   };
   fetch(mbeg);
-  for (long m0 = mbeg; m0 < mend; m0 += (long)R * rpi) {
-    float x[R][8], mu[R], rs[R];
-    float4 d4v[R];
+  for (long m0 = mbeg; m0 < mend; m0 += (long)RR * rpi) {
+    float x[RR][8], mu[RR], rs[RR];
+    float4 d4v[RR];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < RR; ++r) {
       mu[r] = mean[r];
       rs[r] = rstd[r];
       d4v[r] = dp[r];
       xr[r].unpack(x[r]);
     }
-    if (m0 + (long)R * rpi < mend) fetch(m0 + (long)R * rpi);  // next pair: in flight behind this pair's arithmetic
+    if (m0 + (long)RR * rpi < mend) fetch(m0 + (long)RR * rpi);  // next pair: in flight behind this pair's arithmetic
     float gm[8], bt[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) { gm[c] = 0.f; bt[c] = 0.f; }
@@ -126,9 +132,9 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
       load8(hp + lo, gm);
       load8(hp + pw + lo, bt);
     }
-    float g[R][8], s1[R], s2[R];
+    float g[RR][8], s1[RR], s2[RR];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < RR; ++r) {
       const float d4[4] = {d4v[r].x, d4v[r].y, d4v[r].z, d4v[r].w};
       s1[r] = 0.f;
       s2[r] = 0.f;
@@ -181,14 +187,14 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
       }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < RR; ++r) {
       s1[r] = group_sum<G>(s1[r]);
       s2[r] = group_sum<G>(s2[r]);
       s1[r] *= invC;
       s2[r] *= invC;
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < RR; ++r) {
       const long m = m0 + (long)r * rpi + rl;
       if (m >= mend || !vok) continue;
       float o[8];
@@ -320,7 +326,7 @@ static inline int ht_lanes(int pw) { return pw <= 256 ? 32 : 64; }
 static inline long ht_rows_per_block(long M, int G) {
   long r = vkas_cdiv(M > 0 ? M : 1, 1024);
   if (r < 32) r = 32;
-  const long q = (long)R * (256 / G);  // multiple of R * rpi for every NH
+  const long q = (long)(HT_R1 > R ? HT_R1 : R) * (256 / G);  // multiple of the rows per iteration for every NH and OCM
   return vkas_cdiv(r, q) * q;
 }
 
