@@ -59,6 +59,9 @@ constexpr int ABL = VKAS_ABL;
 //      2.7 MB of weights it cycles through instead of thrashing on 5.3 MB                10.4 ms, 7.05 GB   <- shipped
 //   8  the LDS-DMA requests of a READ phase in front of its fragment reads               10.5 ms
 //  32  z leaves with streaming (non-temporal) stores                                     10.5 ms, 8.4 GB (7.03 GB with 4)
+#ifndef VKAS_TN_DEEP
+#define VKAS_TN_DEEP 1
+#endif
 #ifndef VKAS_EXP
 #define VKAS_EXP 4
 #endif
@@ -915,9 +918,13 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const elem_t*
   const unsigned d_step = (unsigned)((long)TN_ROWS * lddy * 2);
   const unsigned c_in2 = (unsigned)c_in << 1;
 
-  elem8 rd[DCH], rx[XCH];
+  // Staging registers.  DEEP (tiles whose register budget allows it): two sets, i.e. the loads of chunk it+2 AND it+3 are in
+  // flight behind chunk it's products - with one set a 64-row iteration lasted as long as a global load takes to return
+  // (~4 200 cycles against 1 536 on the matrix cores)
+  constexpr bool DEEP = VKAS_TN_DEEP && TNn <= 6 && WN * WK >= (VKAS_TN_DEEP > 1 ? 4 : 8);
+  elem8 rdA[DCH], rxA[XCH], rdB[DEEP ? DCH : 1], rxB[DEEP ? XCH : 1];
   long mcur = mbeg;
-  auto load_tile = [&]() {
+  auto load_tile = [&](elem8 (&rd)[DCH], elem8 (&rx)[XCH]) {
     constexpr unsigned OOB = 0xFFFFFFF0u;  // beyond any descriptor: the buffer load returns zeros
 #pragma unroll
     for (int i = 0; i < DCH; ++i) {
@@ -955,7 +962,7 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const elem_t*
     }
     mcur += TN_ROWS;
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, elem8 (&rd)[DCH], elem8 (&rx)[XCH]) {
     elem_t* Ds = lds + buf * TILE;
     elem_t* Xs = Ds + TN_ROWS * LDD;
 #pragma unroll
@@ -986,12 +993,16 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const elem_t*
   const long nrows = mend - mbeg;
   const int nit = (int)((nrows + TN_ROWS - 1) / TN_ROWS);
   if (nit > 0) {
-    load_tile();
-    store_tile(0);
-    if (nit > 1) load_tile();  // registers now hold chunk 1
+    load_tile(rdA, rxA);
+    store_tile(0, rdA, rxA);
+    if (nit > 1) load_tile(rdA, rxA);  // set A now holds chunk 1
+    if constexpr (DEEP) {
+      if (nit > 2) load_tile(reinterpret_cast<elem8(&)[DCH]>(rdB), reinterpret_cast<elem8(&)[XCH]>(rxB));  // set B: chunk 2
+    }
   }
   __syncthreads();
-  for (int it = 0; it < nit; ++it) {
+  // one iteration; rdS / rxS hold chunk it+1 (DEEP: chunk c >= 1 travels in set A when c is odd, in set B when even)
+  auto iteration = [&](int it, elem8 (&rdS)[DCH], elem8 (&rxS)[XCH]) {
     const int buf = it & 1;
     const elem_t* Ds = lds + buf * TILE;
     const elem_t* Xs = Ds + TN_ROWS * LDD;
@@ -1015,12 +1026,20 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const elem_t*
 #pragma unroll
           for (int q = 0; q < 8; ++q) bsum[i] += (float)fd[i][q];
       }
-      if (s == 0 && it + 1 < nit) {  // stage chunk it+1 and reissue the loads of chunk it+2 behind the MFMAs
-        store_tile(buf ^ 1);
-        if (it + 2 < nit) load_tile();
+      if (s == 0 && it + 1 < nit) {  // stage chunk it+1 and reissue loads into the set it leaves behind the MFMAs
+        store_tile(buf ^ 1, rdS, rxS);
+        if (it + (DEEP ? 3 : 2) < nit) load_tile(rdS, rxS);
       }
     }
     __syncthreads();
+  };
+  if constexpr (DEEP) {
+    for (int it = 0; it < nit; it += 2) {
+      iteration(it, rdA, rxA);
+      if (it + 1 < nit) iteration(it + 1, reinterpret_cast<elem8(&)[DCH]>(rdB), reinterpret_cast<elem8(&)[XCH]>(rxB));
+    }
+  } else {
+    for (int it = 0; it < nit; ++it) iteration(it, rdA, rxA);
   }
   // D[row = n_local][col = k_local]: lane holds col = lane&15, rows (lane>>4)*4 + r
 #pragma unroll
