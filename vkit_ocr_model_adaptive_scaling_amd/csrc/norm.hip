@@ -32,6 +32,11 @@ static inline int pick_group(int nvec) {
   return g;
 }
 
+// Tuning knobs of the row kernels, measured with profiles/bench_norm.py at the four stage shapes of config #3 (round 3; the
+// defaults are the fastest): rows in flight per lane group - backward 4 instead of 2: +0...+30 % time (registers cost two of
+// the four waves per SIMD), forward 8: +25 %, 2: same; workgroups per launch 512 / 2048 instead of 1024: +0...+15 %;
+// requesting the next iteration's rows before processing the current ones (LN_BWD_PREFETCH): +10...+30 %; scale-residual
+// backward with 2 / 4 rows per lane and trip: no change.
 #ifndef LN_BWD_R1
 #define LN_BWD_R1 2
 #endif
