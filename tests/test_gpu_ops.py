@@ -84,6 +84,8 @@ CONV_CASES = [
     (2, 136, 512, 64, 200, 3, 1, 1),
     (1, 384, 342, 192, 136, 3, 1, 1),
     (1, 128, 256, 256, 256, 3, 1, 1),  # 128-channel n tiles (the two above pad less with 112)
+    (1, 136, 256, 256, 192, 3, 1, 1),  # 96-channel n tiles (the probability head's width: two full tiles, rotated dy rows)
+    (2, 128, 512, 64, 280, 3, 1, 1),   # ... with an n tail (three tiles, the last 88 wide)
 ]
 
 

@@ -16,6 +16,7 @@ int vkas_gemm_tn_tile_choice(long M, int Np, int K);
 bool vkas_nt_slab_eligible(const vkas_conv_geom* g, int Np);
 bool vkas_tn_slab_eligible(const vkas_conv_geom* g, int Np, long lddy);
 bool vkas_tn_slab_n112(int Np);
+bool vkas_tn_slab_n96(int Np);
 
 static thread_local char g_err[512] = "";
 
@@ -120,7 +121,7 @@ extern "C" int vkas_conv_gemm_kernel_id(int wgrad, const vkas_conv_geom* g, int 
   const long M = (long)g->B * g->Hout * g->Wout;
   const int K = g->KH * g->KW * g->Cp;
   if (wgrad) {
-    if (vkas_tn_slab_eligible(g, Np, lddy)) return 2000 + (vkas_tn_slab_n112(Np) ? 7 : 8);
+    if (vkas_tn_slab_eligible(g, Np, lddy)) return 2000 + (vkas_tn_slab_n96(Np) ? 6 : (vkas_tn_slab_n112(Np) ? 7 : 8));
     return vkas_gemm_tn_tile_choice(M, Np, K);
   }
   int choice = vkas_gemm_nt_tile_choice(M, Np);

@@ -38,6 +38,7 @@ int vkas_gemm_tn_tile_choice(long M, int Np, int K);
 bool vkas_nt_slab_eligible(const vkas_conv_geom* g, int Np);
 bool vkas_tn_slab_eligible(const vkas_conv_geom* g, int Np, long lddy);
 bool vkas_tn_slab_n112(int Np);
+bool vkas_tn_slab_n96(int Np);
 
 namespace {
 
@@ -1106,6 +1107,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const elem_t* _
                                                                  unsigned x_bytes, unsigned dy_bytes) {
   // TNn = 8: 128 output channels per block, dy rows of 256 B with the XOR swizzle.  TNn = 7: 112 channels, rows of
   // 224 B = 56 banks - consecutive rows already start 8 banks apart, the image stays linear (N = 776: 7 tiles, 1% padding).
+  // TNn = 6: 96 channels, rows of 192 B with rotated blocks (N = 192, the probability head: two tiles, no padding).
   constexpr int TK = 3;
   constexpr int BNn = TNn * 16, PD = BNn * 2;  // dy row pitch in bytes
   constexpr int DWI = WG_ROWS * PD / 1024;     // dy wave instructions per chunk (16 or 14)
@@ -1149,10 +1151,19 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const elem_t* _
     if constexpr (TNn == 8) {
       row = 4 * wave + 32 * q + lrow;
       c = lchunk;
-    } else {
+    } else if constexpr (TNn == 7) {
       const int ci = (wave + 8 * q) * 64 + lane;
       row = ci / 14;
       c = ci - row * 14;
+    } else {
+      // TNn = 6: rows of 192 B = 48 banks - rows r and r + 4 would start on the same bank, so the 32-byte blocks of a row are
+      // rotated by (r >> 2) & 3 positions: the 16 rows of a transposing read then sit two per bank group, the minimum
+      static_assert(TNn == 6, "dy staging knows 6, 7 and 8 column tiles");
+      const int ci = (wave + 8 * q) * 64 + lane;
+      row = ci / 12;
+      const int cp = ci - row * 12;                       // position inside the LDS row
+      const int lb = ((cp >> 1) + 6 - ((row >> 2) & 3)) % 6;  // logical block held by that position
+      c = lb * 2 + (cp & 1);
     }
     d_ok[q] = n0 + c * 8 < Np && c * 8 < BNn;
     d_lane[q] = (unsigned)(row * lddy + n0 + c * 8) * 2u;   // + chunk pixel base
@@ -1240,7 +1251,8 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const elem_t* _
   const int fp = (lane & 3) * 8;                         // byte offset of its 4 columns inside the 32-byte block
   unsigned d_addr[TNn], x_addr[TK], x_first[TK], x_last[TK];
 #pragma unroll
-  for (int i = 0; i < TNn; ++i) d_addr[i] = (unsigned)(fr * PD + ((TNn == 8 ? (i ^ (fr & 7)) : i) << 5) + fp);
+  for (int i = 0; i < TNn; ++i)
+    d_addr[i] = (unsigned)(fr * PD + ((TNn == 8 ? (i ^ (fr & 7)) : (TNn == 6 ? (i + (fr >> 2)) % 6 : i)) << 5) + fp);
 #pragma unroll
   for (int j = 0; j < TK; ++j) {
     const int r = fr + x_shift[j];
@@ -1459,6 +1471,12 @@ extern "C" int vkas_trace_read(void* dst, size_t bytes) {
 }
 #endif
 bool vkas_tn_slab_n112(int Np) { return vkas_cdiv(Np, 112) * 112 < vkas_cdiv(Np, 128) * 128; }  // 112-wide tiles pad less
+// 96-wide tiles when they pad less than both wider ones (N = 192: no padding against 224 / 256 columns)
+bool vkas_tn_slab_n96(int Np) {
+  static const bool off = getenv("VKAS_TN_NO96") != nullptr;
+  const long p96 = vkas_cdiv(Np, 96) * 96;
+  return !off && p96 < vkas_cdiv(Np, 112) * 112 && p96 < vkas_cdiv(Np, 128) * 128;
+}
 
 #endif  // VKAS_MFMA_F16
 
@@ -1577,8 +1595,9 @@ int VKAS_MFMA_FN(vkas_gemm_tn_mfma)(const void* x, const vkas_conv_geom* g, cons
   const long x_bytes = (((long)g->B * g->Hin * g->Win - 1) * g->ldx + g->Cp) * 2;
   const long dy_bytes = ((M - 1) * lddy + Np) * 2;
   if (!x_gelu && vkas_tn_slab_eligible(g, Np, lddy)) {
-    const bool n112 = vkas_tn_slab_n112(Np);
-    const long tiles = vkas_cdiv(Np, n112 ? 112 : 128) * 3 * vkas_cdiv(g->Cp, 128);
+    const bool n96 = vkas_tn_slab_n96(Np);
+    const bool n112 = !n96 && vkas_tn_slab_n112(Np);
+    const long tiles = vkas_cdiv(Np, n96 ? 96 : (n112 ? 112 : 128)) * 3 * vkas_cdiv(g->Cp, 128);
     const long chunks = M / 64;
     // Pixel splits: whole splits per XCD (multiple of 8).  The tiles of one split walk the same dy / x chunks at the same
     // time and share them through that XCD's L2 (every operand byte is used by 9 tiles): keeping a split's tiles
@@ -1589,7 +1608,11 @@ int VKAS_MFMA_FN(vkas_gemm_tn_mfma)(const void* x, const vkas_conv_geom* g, cons
     if (splits > chunks / 16) splits = chunks / 16 > 0 ? chunks / 16 : 1;
     const long cps = vkas_cdiv(chunks, splits);
     splits = vkas_cdiv(chunks, cps);
-    if (n112)
+    if (n96)
+      conv3x3_wgrad_slab_kernel<6><<<(unsigned)(tiles * splits), 512, 0, st>>>((const elem_t*)x, *g, (const elem_t*)dy, lddy, Np, M,
+                                                                               K, (int)cps, gw, gb, (unsigned)x_bytes,
+                                                                               (unsigned)dy_bytes);
+    else if (n112)
       conv3x3_wgrad_slab_kernel<7><<<(unsigned)(tiles * splits), 512, 0, st>>>((const elem_t*)x, *g, (const elem_t*)dy, lddy, Np, M,
                                                                                K, (int)cps, gw, gb, (unsigned)x_bytes,
                                                                                (unsigned)dy_bytes);
