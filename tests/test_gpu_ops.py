@@ -403,6 +403,26 @@ def test_adaptive_avgpools_one_node(dtype):
     close(from_act(xb.grad, 24), xr2.grad, dtype, 'avgpools bwd, one branch')
 
 
+def test_finalize_many_sums_partial_rows():
+    """vkas_finalize_many: up to 8 second-stage column sums per launch (ops.finalize_many batches more), each over its own
+    number of partial rows / columns / row pitch / first column, written or added onto the output."""
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(77)
+    items, expect = [], []
+    for k in range(11):  # two launches
+        P, n = int(torch.randint(1, 300, (1,), generator=g)), int(torch.randint(1, 200, (1,), generator=g))
+        col0 = int(torch.randint(0, 40, (1,), generator=g))
+        ld = col0 + n + int(torch.randint(0, 9, (1,), generator=g))
+        ws = torch.randn(P, ld, generator=g).cuda()
+        acc = k % 3 == 1
+        out = torch.randn(n, generator=g).cuda() if acc else torch.full((n,), float('nan'), device='cuda')
+        expect.append(ws[:, col0:col0 + n].double().sum(0) + (out.double() if acc else 0.0))
+        items.append((ws.view(-1), col0, P, n, ld, out, acc))
+    ops.finalize_many(items)
+    for (_, _, P, n, _, out, _), ref in zip(items, expect):
+        assert float((out.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), (P, n)
+
+
 def test_zero_arena_hands_out_clean_disjoint_slices():
     """ops.zeros_f32 / zero_arena_reset (the per-step scratch of the weight-gradient images): before the first reset every
     request is a fresh torch.zeros; after a reset requests are disjoint, zeroed slices of one buffer until it is exhausted, then
