@@ -473,10 +473,12 @@ __global__ __launch_bounds__(512, 4) void dwconv7x7_mfma_kernel(const T* __restr
     const T* xb = x + (((long)b * H + (y0 - 3)) * W + (x0 - 3)) * ldx + c0 + chunk * 8;
 #pragma unroll
     for (int k = 0; k < NSTG; ++k) {
-      const int iy = item_yx[k] >> 8, ix = item_yx[k] & 255;
+      int yx = item_yx[k];
+      asm volatile("" : "+v"(yx));  // opaque: addresses derived from it are recomputed per tile, not kept (and spilled)
+      const int iy = yx >> 8, ix = yx & 255;
       const int gy = y0 + iy - 3, gx = x0 + ix - 3;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (item_yx[k] >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c_ok && !(DW_ABL & 8))
+      if (yx >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c_ok && !(DW_ABL & 8))
         v = *reinterpret_cast<const uint4*>(xb + ((long)iy * W + ix) * ldx);
       sv[k] = v;
     }
@@ -485,8 +487,10 @@ __global__ __launch_bounds__(512, 4) void dwconv7x7_mfma_kernel(const T* __restr
   auto stage = [&]() {
 #pragma unroll
     for (int k = 0; k < NSTG; ++k) {
-      if (item_yx[k] >= 0 && !(DW_ABL & 2)) {
-        const int iy = item_yx[k] >> 8, ix = item_yx[k] & 255;
+      int yx = item_yx[k];
+      asm volatile("" : "+v"(yx));
+      if (yx >= 0 && !(DW_ABL & 2)) {
+        const int iy = yx >> 8, ix = yx & 255;
         unsigned short* dst = reinterpret_cast<unsigned short*>(in_planes) + chunk * MPB_IN + iy * MIP + ix + 5;
         const unsigned wd[4] = {sv[k].x, sv[k].y, sv[k].z, sv[k].w};
 #pragma unroll
@@ -515,6 +519,11 @@ __global__ __launch_bounds__(512, 4) void dwconv7x7_mfma_kernel(const T* __restr
     DW_TR(0);
 
     // ---- compute: 7 MFMAs per (channel, 16-column group); D[i][j]: lane holds out x = 4g .. 4g+3 of row j = li
+    // (lane / thread indices opaque per tile: the LDS addresses and item coordinates derived from them are a few integer
+    // operations each - kept across tiles they were 19 spilled registers, reloaded through vmcnt behind the prefetch)
+    int lane_t = lane, tid_t = tid;
+    asm volatile("" : "+v"(lane_t), "+v"(tid_t));
+    const int li = lane_t & 15, g = lane_t >> 4;
 #pragma unroll
     for (int cc = 0; cc < ((DW_ABL & 1) ? 0 : 2); ++cc) {
       const int cl = wave * 2 + cc;
@@ -548,7 +557,7 @@ __global__ __launch_bounds__(512, 4) void dwconv7x7_mfma_kernel(const T* __restr
     constexpr int NOUT = (DW_ABL & 4) ? 0 : MTY * MTX * 2 / NTHR;
 #pragma unroll 1
     for (int k = 0; k < NOUT; ++k) {
-      const int it = tid + k * NTHR;
+      const int it = tid_t + k * NTHR;
       const int chunk = it & 1, q = it >> 1;
       const int oy = q / MTX, ox = q - oy * MTX;
       const int gy = y0 + oy, gx = x0 + ox;
