@@ -226,6 +226,7 @@ def run_forward_config(args, world, rank, device, dist):
         sync()
         elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
+    coll_per_step = ((reducer.collectives_issued - coll0) / args.steps) if reducer is not None else 0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -331,7 +332,13 @@ def main():
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
-    if world > 1:
+    # VKAS_FORCE_REDUCER=1 at N = 1: the bucketed reducer issues its (one-rank) RCCL all-reduces anyway - the N > 1 code
+    # path measured on a one-GPU box (the line then carries config.collective.forced = true; never the default)
+    force_reducer = world == 1 and os.environ.get('VKAS_FORCE_REDUCER', '0') == '1' and args.config == 3
+    if force_reducer:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+    if world > 1 or force_reducer:
         dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.config != 3:
@@ -346,7 +353,7 @@ def main():
                             compute_dtype=dtype).to(device).train()
     flat = FlatBuffers(model.named_parameters())
     opt = FlatAdamW(None, lr=8e-4, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=2.5, flat=flat)
-    reducer = BucketedGradReducer(flat, adaptive_scaling_buckets(model)) if world > 1 else None
+    reducer = BucketedGradReducer(flat, adaptive_scaling_buckets(model)) if (world > 1 or force_reducer) else None
     step = TwoPassStep(model, AdaptiveScalingRoughLossFunction(AdaptiveScalingRoughLossFunctionConifg()),
                        AdaptiveScalingPreciseLossFunction(AdaptiveScalingPreciseLossFunctionConifg()), opt, reducer,
                        merge_backbone=(args.schedule == 'merged'))
@@ -366,6 +373,7 @@ def main():
         it += 1
     sync()
     ops.TIMER = ops.LaunchTimer()
+    coll0 = reducer.collectives_issued if reducer is not None else 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = step(rough, precise, lr=cosine_warm_restarts_lr(it / 1000.0, 8e-4, 8e-6, 10, 10))
@@ -456,8 +464,10 @@ def main():
                                                            f'(BASELINE.json configs[2]{"/[3]" if world > 1 else ""})',
                                                'global_batch': args.batch * world, 'images_per_step': images,
                                                'parallelism': f'dp{world}', 'pass_schedule': args.schedule,
-                                               'collective': ({'backend': dist.get_backend(), 'world_size': dist.get_world_size()}
-                                                              if world > 1 else {'backend': None, 'world_size': 1}),
+                                               'collective': ({'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                                                               'forced': force_reducer,
+                                                               'all_reduces_per_step': coll_per_step}
+                                                              if reducer is not None else {'backend': None, 'world_size': 1}),
                                                'label_point_backward': 'compact (B*P rows)' if ops._POINT_SPARSE else 'dense',
                                                'per_pass': per_pass,
                                                'host_enqueue_ms_per_step': round(1000.0 * enqueue / args.steps, 2),
@@ -466,7 +476,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(hw, 1337)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_reducer:
         dist.destroy_process_group()
 
 

@@ -244,6 +244,11 @@ int vkas_adaptive_avgpool_bwd(const void* dy, long lddy, void* dx, long lddx, in
 /* y[m][0..Cp) = x[m][0..Cp) (+ y if accumulate): channel-slice copies for concat / its backward */
 int vkas_copy_channels(const void* x, long ldx, void* y, long ldy, long M, int Cp, int accumulate, int dtype,
                        void* stream);
+/* y[m][c_dst + c] = x[m][c_src + c] for c in [0, C), then zero_tail zero channels behind them; channel offsets are
+   element-granular (no 8-channel alignment): torch.cat of parts whose widths are not multiples of 8 - e.g.
+   FpnNeck(..., out_channels=400) -> 4 x 100 channels, fpn.py:75,144; upernext.py:82,144,197 - and its backward */
+int vkas_copy_channel_range(const void* x, long ldx, int c_src, void* y, long ldy, int c_dst, long M, int C,
+                            int zero_tail, int dtype, void* stream);
 /* nn.Softplus() on fp32 maps: adaptive_scaling.py:101,140 */
 int vkas_softplus_fwd(const float* x, float* y, long n, void* stream);
 int vkas_softplus_bwd(const float* x, const float* dy, float* dx, long n, void* stream);

@@ -13,6 +13,9 @@ RESIZE_CASES = ((6, 6, 32, 32), (3, 3, 32, 32), (1, 1, 32, 32), (2, 2, 32, 32), 
                 (3, 5, 6, 10), (16, 16, 32, 32))
 POOL_CASES = ((20, 20, 3), (20, 20, 6), (32, 32, 3), (32, 32, 1), (3, 5, 6), (8, 8, 2), (10, 16, 6))
 TAIL_POINTS = np.array([-40.0, -9.0, -6.0, -3.0, -1.0, -0.5, -1e-3, 0.0, 1e-3, 0.5, 1.0, 3.0, 3.3333, 3.4, 6.0, 9.0, 40.0])
+# the reference's own test widths that are not multiples of 8 (tests/test_fpn.py:16-28: out_channels=400 -> 4 x 100)
+WIDTH400 = dict(seed=61, std=0.08, head_std=0.05, in_channels_group=(96, 192, 384, 768), out_channels=400, batch=1,
+                base_hw=(16, 24))
 LOSS_TOY = dict(seed=41, batch=2, shape=(80, 72), core_box=(10, 69, 6, 65), points=20)
 FULL_MODEL = dict(seed=51, std=0.05, image=(1, 3, 256, 256), down_shape=(128, 128), core_box=(10, 117, 10, 117),
                   points=50)

@@ -7,6 +7,7 @@ import torch
 from tests.golden import recipe
 from vkit_ocr_model_adaptive_scaling_amd.utils import portable_rng as prng
 
+FMT_CEILING = 6e-2  # largest relative error a single tensor may claim from the 16-bit storage format (see check_grad_summary)
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
@@ -45,7 +46,8 @@ def check_grad_summary(named_grads, g, tol, prefix='', min_checked=1, skip_missi
     tag: record the worst measured errors in the parity report under this name.
     fmt_grads (16-bit storage modes): name -> the same gradient from the ORACLE with its stored activations rounded to the
     storage type (oracle.storage_rounding: the error of the format alone, no kernels).  A parameter may then exceed ``tol``
-    only as far as twice what the format alone does to that very statistic of that very parameter."""
+    only as far as twice what the format alone does to that very statistic of that very parameter, and never beyond
+    FMT_CEILING."""
     names = [k[len(prefix) + 6:] for k in g.files if k.startswith(prefix + 'gnorm/')]
     assert len(names) >= min_checked
     gmax = max(float(g[f'{prefix}gnorm/{n}']) for n in names)
@@ -69,11 +71,14 @@ def check_grad_summary(named_grads, g, tol, prefix='', min_checked=1, skip_missi
             q = fmt_grads[n].detach().double().cpu().reshape(-1)
             fmt_n = abs(float(q.norm()) - ref_norm)
             fmt_s = float(np.linalg.norm(q[recipe.sample_indices(q.numel())].numpy() - ref_samp))
-        assert abs(float(gr.norm()) - ref_norm) <= max(tol * ref_norm, 2.0 * fmt_n) + floor, (n, float(gr.norm()), ref_norm, fmt_n)
+        # the format-error allowance is capped: no parameter may lean on it beyond FMT_CEILING (relative)
+        cap = max(tol, FMT_CEILING)
+        assert abs(float(gr.norm()) - ref_norm) <= min(max(tol * ref_norm, 2.0 * fmt_n), cap * ref_norm) + floor, (
+            n, float(gr.norm()), ref_norm, fmt_n)
         rms = ref_norm / max(1.0, np.sqrt(gr.numel()))
         denom = max(float(np.linalg.norm(ref_samp)), rms * np.sqrt(len(ref_samp)))
         serr = float(np.linalg.norm(samp - ref_samp))
-        assert serr <= max(tol * denom, 2.0 * fmt_s) + floor * np.sqrt(len(ref_samp)), (
+        assert serr <= min(max(tol * denom, 2.0 * fmt_s), cap * denom) + floor * np.sqrt(len(ref_samp)), (
             n, serr / max(denom, 1e-300), fmt_s / max(denom, 1e-300))
         if ref_norm > 1e-3 * gmax:
             worst_norm = max(worst_norm, (abs(float(gr.norm()) - ref_norm) / ref_norm, n))

@@ -393,7 +393,54 @@ def test_torch_jit_script_owns_the_reference_schema_and_refuses_the_cpu(tmp_path
     del jit, model
     loaded = torch.jit.load(path)
     assert len(loaded.state_dict()) == 304 and loaded._script_spec.count('upernext') == 1
-    # the operator's kernel rebuilds an eager module around the loaded tensors (no copy)
-    eager = scripting._model_for(list(loaded.parameters()), loaded._script_spec)
-    assert all(a is b for a, b in zip(eager.parameters(), loaded.parameters()))
-    assert eager.compute_dtype == torch.bfloat16
+    # the operator's kernel binds the loaded tensors into a parameter-less skeleton of the eager module for the duration of a
+    # call (no copy) and unbinds them afterwards: nothing keeps the parameters alive once the scripted module is gone
+    params = list(loaded.parameters())
+    with scripting._Bound('test', params, loaded._script_spec, False) as eager:
+        assert all(a is b for a, b in zip(eager.parameters(), params))
+        assert eager.compute_dtype == torch.bfloat16 and not eager.training
+    assert all(p.is_meta for p in eager.parameters())
+    with pytest.raises(RuntimeError, match='parameter tensors'):
+        scripting._Bound('test', params[:-1], loaded._script_spec, False)
+
+
+def test_sub_modules_script_on_the_host_with_the_reference_schema():
+    """tests/test_convnext.py:53-63, test_fpn.py:30,49, test_upernext.py:30 of the reference script the backbone, the necks and
+    the heads on their own: every scriptable class of the mirror compiles without a GPU, keeps the reference's state-dict
+    keys on the eager module's tensors, and its compiled forward is ONE call of vkas::module_forward (which fails loudly on a
+    CPU tensor; running it is tests/test_gpu_reference_tests.py)."""
+    import json
+    from vkit_ocr_model_adaptive_scaling_amd.model import ConvNext, FpnNeck, FpnHead, UperNextNeck, UperNextHead
+    from vkit_ocr_model_adaptive_scaling_amd.model.convnext import ConvNextBlock, ConvNextBlockLayer
+    from vkit_ocr_model_adaptive_scaling_amd.model.upernext import PpmBlock
+    from vkit_ocr_model_adaptive_scaling_amd.model import scripting
+    cases = [ConvNext.create_tiny(stem_use_pconv2x2=True), FpnNeck((96, 192, 384, 768), 400), FpnHead(400, 1, 2),
+             UperNextNeck((96, 192, 384, 768), 384), UperNextHead(64, 2, 2, 0.5), ConvNextBlock(0, 5, 24, 2, 48),
+             ConvNextBlockLayer(40, 0.05), PpmBlock((1, 2, 3, 6), 72, 20)]
+    for m in cases:
+        jit = torch.jit.script(m)
+        name = type(m).__name__
+        assert list(jit.state_dict()) == list(m.state_dict()), name
+        assert all(a.data_ptr() == b.data_ptr() for a, b in zip(jit.parameters(), m.parameters())), name
+        assert 'vkas::module_forward' in str(jit.forward.graph), name
+        spec = json.loads(jit._script_spec)
+        assert spec['cls'] == name and spec['compute_dtype'] == 'bf16'
+        # the recipe rebuilds the same structure (parameter names and shapes) on the meta device
+        skeleton, slots = scripting._skeleton(jit._script_spec)
+        assert [(n, tuple(p.shape)) for _, _, p, n in slots] == [(n, tuple(p.shape)) for n, p in m.named_parameters()], name
+    x = torch.zeros(1, 3, 64, 64)
+    with pytest.raises(RuntimeError, match='MI355X only'):
+        torch.jit.script(cases[0])(x)
+    scripting.clear()
+
+
+def test_necks_accept_the_reference_tests_widths():
+    """tests/test_fpn.py:16-28 builds FpnNeck((96, 192, 384, 768), out_channels=400); the reference only asks for
+    out_channels % len(levels) == 0 (fpn.py:75, upernext.py:144)."""
+    from vkit_ocr_model_adaptive_scaling_amd.model import FpnNeck, UperNextNeck
+    assert FpnNeck((96, 192, 384, 768), 400).inner_channels == 100
+    assert UperNextNeck((96, 192, 384, 768), 400).inner_channels == 100
+    with pytest.raises(AssertionError):
+        FpnNeck((96, 192, 384, 768), 402)
+    with pytest.raises(AssertionError):
+        UperNextNeck((96, 192, 384, 768), 402)

@@ -10,7 +10,7 @@ import torch
 
 from oracle import torch_oracle as O
 from tests.golden import recipe
-from tests.helpers import golden, rel_err, check_grad_summary
+from tests.helpers import golden, rel_err, check_grad_summary, FMT_CEILING
 from vkit_ocr_model_adaptive_scaling_amd.utils import portable_rng as prng
 
 pytestmark = pytest.mark.gpu
@@ -21,18 +21,23 @@ IDS = ['f32', 'bf16', 'f16']
 # gradient buffer) is asserted by test_flat_gradient_north_star.  The bounds below are for SINGLE tensors of deliberately
 # harsh toy networks (layer scale ~1, weights std 0.05..0.2, up to 60 roundings deep): a single feature map or a single
 # parameter's gradient carries up to 2.4e-2 of error from bf16 STORAGE alone (the oracle with its stored activations rounded
-# to bf16, no kernels involved: profiles/parity_r03.txt), so they sit at 3e-2; fp16 (BASELINE.json configs[4], 11 significant
-# bits against 8) is held to a quarter of that.  Measured values of every test: profiles/parity_r03.txt.
+# to bf16, no kernels involved: profiles/parity_r04.txt), so they sit at 3e-2; fp16 (BASELINE.json configs[4], 11 significant
+# bits against 8) is held to a quarter of that.  Measured values of every test: profiles/parity_r04.txt.
 FWD_TOL = {torch.float32: 1e-3, torch.bfloat16: 2e-2, torch.float16: 5e-3}
 GRAD_TOL = {torch.float32: 2e-3, torch.bfloat16: 3e-2, torch.float16: 7.5e-3}
 
 
+# FMT_CEILING (tests/helpers.py): no single tensor may lean on the format-error allowance beyond it (the largest format error
+# of a single tensor measured on the harsh toy / golden parameter sets is 2.4e-2 in bf16)
 def fmt_bound(tol, fmt_err):
     """Bound of ONE tensor (a feature map, one parameter's gradient) in a 16-bit storage mode: ``tol``, or - where the storage
     FORMAT alone (the oracle with its stored activations rounded to that type, no kernels: oracle.storage_rounding) already
     takes that tensor beyond it - twice that format error: the kernels' roundings are as many again and independent of the
     oracle's.  The same rule as test_flat_gradient_north_star applies per parameter."""
-    return max(tol, 2.0 * fmt_err + 2e-3)
+    if fmt_err <= 0.0:  # fp32 mode: no storage rounding to allow for - the north-star bound itself
+        return tol
+    return min(max(tol, 2.0 * fmt_err + 2e-3), max(tol, FMT_CEILING))
+
 
 
 def _storage(dtype):
@@ -323,9 +328,11 @@ def test_flat_gradient_north_star(kind, init, dtype):
     What 16-bit STORAGE alone costs is measured, not guessed: the oracle with every stored activation / matrix operand
     rounded to the storage type (oracle.storage_rounding; fp64 arithmetic, no kernels).  On the harsh parameter set that
     alone puts the flat gradient at 1.2e-2 and single buckets at 1.1e-2 .. 1.6e-2 in bf16 (reference_init: well inside the
-    bound), so the assertions are: losses within the north-star bound outright; the flat gradient within the bound, or within
-    15% of the format error where that alone exceeds the bound; a bucket likewise within 25%; a single parameter within the
-    bound OR within 2x of the storage-format error of the same parameter.  (The distance between the kernels and the rounded
+    bound), so the assertions are: losses within the north-star bound outright; the flat gradient within
+    max(1e-2, the error of the REFERENCE's own bf16 autocast run on the same recipe - a reference-held fixture); a bucket within
+    25% of the format error where that exceeds the bound; a single parameter within the bound OR within 2x of the
+    storage-format error of the same parameter (capped at FMT_CEILING), with no more parameters beyond 1e-2 - and none further
+    out - than in the reference's own bf16 run.  (The distance between the kernels and the rounded
     oracle is recorded, not bounded: they are two independent sets of roundings of the same format.)"""
     scale = 1024.0 if dtype == torch.float16 else 1.0
     std, bs = (None, None) if init == 'golden' else (0.02, 1e-6)
@@ -377,15 +384,45 @@ def test_flat_gradient_north_star(kind, init, dtype):
         qworst = max(qerr, key=qerr.get)
         _rec(tag, 'worst single parameter', perr[worst], None, '%s (format error of it %.3e)' % (worst, qerr[worst]))
         _rec(tag, 'worst single parameter of the storage-rounded oracle', qerr[qworst], None, qworst)
-        over = {n: (perr[n], qerr[n]) for n in names if perr[n] > fmt_bound(bound, qerr[n])}
+        # gradients the storage format alone destroys (fp16 from the reference's initialisation: block_scale = 1e-6 times an
+        # fp16 activation gradient underflows to zero even with the x1024 loss scale - in the storage-rounded oracle exactly as
+        # in the kernels; INTEGRATION.md lists it) are counted, not bounded; bf16 has none
+        dead = [n for n in names if qerr[n] >= 0.5]
+        _rec(tag, 'parameters whose gradient the storage format alone destroys (format error >= 0.5)', len(dead), None,
+             'of %d' % len(names))
+        assert dtype == torch.float16 or not dead, dead
+        over = {n: (perr[n], qerr[n]) for n in names if n not in dead and perr[n] > fmt_bound(bound, qerr[n])}
         _rec(tag, 'parameters over the bound', sum(e > bound for e in perr.values()), None,
              'of %d; %d of them beyond 2x their format error' % (len(names), len(over)))
         print(tag, 'format error: flat', qflat, 'kernels vs rounded oracle', kq, 'over', over)
         assert not over, over
-        # the whole vector: the north-star bound outright - or, on a parameter set where the FORMAT alone exceeds it (the harsh
-        # golden set in bf16: 1.2e-2 with no kernel involved), within 15% of that format error
-        fb = max(bound, 1.15 * qflat)
-        _rec(tag, 'flat gradient: asserted bound', flat_err, fb, 'format alone %.3e' % qflat)
+        # the whole vector: the north-star bound outright - or, where the REFERENCE ITSELF exceeds it in bf16 (its model under
+        # torch.autocast('cpu', bfloat16) against its own fp32 run on this very recipe and parameter set:
+        # tests/golden/ref_autocast_bf16.npz, written by make_golden_r04.py from the imported reference), that reference-held
+        # number.  fp16 (three more significant bits) has to meet the bound outright.
+        if dtype == torch.bfloat16:
+            ra = golden('ref_autocast_bf16')
+            key = f'{kind}/{init}/'
+            ref_flat = float(ra[key + 'flat_grad_rel_err'])
+            fb = max(bound, ref_flat)
+            _rec(tag, 'flat gradient: asserted bound = max(1e-2, the reference\'s own bf16 autocast error)', flat_err, fb,
+                 'reference under autocast %.3e; storage-rounded oracle %.3e' % (ref_flat, qflat))
+            for b in sorted(buckets):
+                _rec(tag, f'bucket {b}: the reference under bf16 autocast (recorded)', float(ra[key + 'bucket/' + b]), None)
+            # single parameters: no more of them beyond 1e-2, and none further out, than in the reference's own bf16 run
+            n_over = sum(e > bound for e in perr.values())
+            ref_over, ref_n = int(ra[key + 'params_over_1e-2']), int(ra[key + 'num_params'])
+            ref_worst = float(ra[key + 'worst_param_rel_err'])
+            live = [n for n in names if float(want[n].norm()) > 1e-6 * max(float(want[m].norm()) for m in names)]
+            worst_live = max(perr[n] for n in live)
+            _rec(tag, 'parameters beyond 1e-2 (reference under autocast: %d of %d)' % (ref_over, ref_n), n_over,
+                 1.1 * ref_over + 8)
+            _rec(tag, 'worst parameter with a non-zero gradient (reference under autocast: %.3e)' % ref_worst, worst_live, ref_worst)
+            assert n_over <= 1.1 * ref_over + 8, (n_over, ref_over)
+            assert worst_live <= ref_worst, (worst_live, ref_worst)
+        else:
+            fb = bound
+            _rec(tag, 'flat gradient: asserted bound', flat_err, fb, 'format alone %.3e' % qflat)
         assert flat_err < fb, (flat_err, qflat)
         return
     assert flat_err < bound, flat_err

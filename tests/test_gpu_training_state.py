@@ -1,0 +1,112 @@
+"""Optimizer-state and gradient-buffer behaviour the round-3 review asked to pin:
+
+* the RestoreState export holds state for exactly the parameters ``torch.optim.AdamW`` would (a parameter whose gradient was
+  exactly zero HAS state, one that never received a gradient has none) - train.py:287-298,599-605;
+* on resume the checkpoint's betas / weight decay win over the config record, as in the reference (optimizer.load_state_dict
+  after construction, train.py:304-322);
+* a gradient handed to autograd is never a view of the per-step zero arena: ``set_to_none`` -> backward -> ``zero_grad`` keeps
+  the adopted gradients intact."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_exported_optimizer_state_keys_match_torch_adamw(tmp_path):
+    from vkit_ocr_model_adaptive_scaling_amd.training import FlatBuffers, FlatAdamW
+    from vkit_ocr_model_adaptive_scaling_amd.training.checkpoint import optimizer_state_dict, load_optimizer_state_dict
+    dev = torch.device('cuda')
+    torch.manual_seed(0)
+
+    def params():
+        torch.manual_seed(1)
+        return [torch.nn.Parameter(torch.randn(s, device=dev)) for s in ((5, 3), (7,), (2, 2, 2), (4,))]
+
+    ours, theirs = params(), params()
+    flat = FlatBuffers([(f'p{i}', p) for i, p in enumerate(ours)])
+    opt = FlatAdamW(None, lr=1e-2, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=None, flat=flat)
+    ref = torch.optim.AdamW(theirs, lr=1e-2, betas=(0.9, 0.999), weight_decay=0.01)
+    for it in range(3):
+        # p0: a real gradient; p1: a gradient that is exactly zero; p2: never any gradient (a head no pass runs); p3: real
+        for ps in (ours, theirs):
+            loss = (ps[0] ** 2).sum() * (it + 1) + (ps[1] * 0.0).sum() + ps[3].sum()
+            loss.backward()
+        opt.step()
+        opt.zero_grad()
+        ref.step()
+        ref.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    sd, rsd = optimizer_state_dict(opt), ref.state_dict()
+    assert sorted(sd['state']) == sorted(rsd['state']) == [0, 1, 3]
+    for i in sd['state']:
+        assert float(sd['state'][i]['step']) == float(rsd['state'][i]['step']) == 3.0
+        assert torch.allclose(sd['state'][i]['exp_avg'], rsd['state'][i]['exp_avg'].cpu(), rtol=1e-5, atol=1e-7)
+        assert torch.allclose(sd['state'][i]['exp_avg_sq'], rsd['state'][i]['exp_avg_sq'].cpu(), rtol=1e-5, atol=1e-9)
+    for a, b in zip(ours, theirs):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    # round trip: the key set survives load + export, and torch.optim.AdamW accepts the file
+    opt2 = FlatAdamW(None, flat=FlatBuffers([(f'p{i}', p) for i, p in enumerate(params())]))
+    load_optimizer_state_dict(opt2, sd)
+    assert sorted(optimizer_state_dict(opt2)['state']) == [0, 1, 3] and opt2.step_count == 3
+    torch.optim.AdamW(params()).load_state_dict(sd)
+
+
+def test_resume_keeps_the_checkpoints_hyper_parameters(tmp_path):
+    from vkit_ocr_model_adaptive_scaling_amd.training import FlatBuffers, FlatAdamW, EpochConfig, OptimizerConfig, run_training
+    from vkit_ocr_model_adaptive_scaling_amd.training.checkpoint import optimizer_state_dict, load_optimizer_state_dict
+    dev = torch.device('cuda')
+    p = [torch.nn.Parameter(torch.randn(8, device=dev))]
+    saved = FlatAdamW(None, betas=(0.8, 0.95), weight_decay=0.2, flat=FlatBuffers([('p', p[0])]))
+    sd = optimizer_state_dict(saved)
+
+    class Step:  # the slots run_training reads before its first batch
+        world = 1
+
+        def __init__(self, optimizer):
+            self.optimizer = optimizer
+            self.model = torch.nn.Linear(1, 1)
+
+    oc = OptimizerConfig(adamw_betas=(0.9, 0.999), adamw_weight_decay=0.01, clip_grad_norm_max_norm=1.5)
+    ec = EpochConfig(num_epochs=0)
+    fresh = FlatAdamW(None, betas=(0.5, 0.5), weight_decay=0.5, max_grad_norm=9.0, flat=FlatBuffers([('p', torch.nn.Parameter(torch.randn(8, device=dev)))]))
+    run_training(Step(fresh), lambda e: [], lambda: [], ec, oc, str(tmp_path), dev)
+    assert fresh.betas == (0.9, 0.999) and fresh.weight_decay == 0.01 and fresh.max_grad_norm == 1.5   # a new run: the config
+    resumed = FlatAdamW(None, flat=FlatBuffers([('p', torch.nn.Parameter(torch.randn(8, device=dev)))]))
+    load_optimizer_state_dict(resumed, sd)
+    run_training(Step(resumed), lambda e: [], lambda: [], ec, oc, str(tmp_path), dev, start_epoch_idx=0)
+    assert tuple(resumed.betas) == (0.8, 0.95) and resumed.weight_decay == 0.2   # a resumed run: the checkpoint
+    assert resumed.max_grad_norm == 1.5                                          # the clip norm is no optimizer state
+
+
+def test_gradients_adopted_by_autograd_survive_the_arena_reset():
+    """set_to_none -> backward -> zero_grad with the step's zero arena live (ops._ZeroArena): a bias gradient returned to
+    autograd (N not a multiple of 8, so the packed bias row is not the parameter's view) must not be a slice of the arena."""
+    from vkit_ocr_model_adaptive_scaling_amd import ops
+    from vkit_ocr_model_adaptive_scaling_amd.model import UperNextHead
+    from vkit_ocr_model_adaptive_scaling_amd.training import FlatBuffers
+    dev = torch.device('cuda')
+    torch.manual_seed(2)
+    head = UperNextHead(24, 2, 1).to(dev)          # inner width (24 + 2) // 2 = 13: padded to 16 columns
+    flat = FlatBuffers(head.named_parameters())
+    x = torch.randn(2, 24, 12, 20, device=dev)
+
+    def grads():
+        head(x).float().square().sum().backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in head.named_parameters()}
+
+    flat.zero_grad()            # arms the arena
+    want = grads()
+    flat.zero_grad()
+    for p in head.parameters():
+        p.grad = None           # set_to_none: autograd now ADOPTS what the ops return
+    got = grads()
+    held = {n: p.grad for n, p in head.named_parameters()}
+    ops.zero_arena_reset()      # what the next flat.zero_grad() does to the arena
+    torch.cuda.synchronize()
+    for n in want:
+        assert float(want[n].abs().max()) > 0 or n.endswith('step1_conv3x3.0.bias'), n
+        assert torch.allclose(got[n], want[n], rtol=2e-2, atol=1e-3 * float(want[n].abs().max()) + 1e-12), n
+        assert torch.equal(held[n], got[n]), f'{n}: the adopted gradient changed when the arena was reset'
+    flat.zero_grad()            # re-attaches the flat views
+    assert all(flat.grad_view_ok(i) for i in range(len(flat.params)))

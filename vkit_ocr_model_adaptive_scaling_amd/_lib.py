@@ -116,6 +116,7 @@ _SIGS = {
     'vkas_adaptive_avgpool_fwd': (c_int, [_P, c_long, _P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'vkas_adaptive_avgpool_bwd': (c_int, [_P, c_long, _P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'vkas_copy_channels': (c_int, [_P, c_long, _P, c_long, c_long, c_int, c_int, c_int, _P]),
+    'vkas_copy_channel_range': (c_int, [_P, c_long, c_int, _P, c_long, c_int, c_long, c_int, c_int, c_int, _P]),
     'vkas_softplus_fwd': (c_int, [_P, _P, c_long, _P]),
     'vkas_softplus_bwd': (c_int, [_P, _P, _P, c_long, _P]),
     'vkas_rough_loss_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -224,6 +224,21 @@ __global__ void copy_channels_kernel(const T* __restrict__ x, long ldx, T* __res
   }
 }
 
+// Element-granular channel-range copy: y[m][c_dst + c] = c < C ? x[m][c_src + c] : 0 for c in [0, C + zero_tail).
+// torch.cat of parts whose widths are not multiples of 8 (fpn.py:144 with out_channels = 400 -> 4 x 100 channels;
+// upernext.py:82,197) lays the parts side by side WITHOUT pad channels, so a part starts at a 2-byte granular offset: the
+// 16-byte vector kernels cannot address it.  Lanes run along the channels of a pixel (coalesced 2- / 4-byte accesses).
+template <typename T>
+__global__ void copy_channel_range_kernel(const T* __restrict__ x, long ldx, int c_src, T* __restrict__ y, long ldy, int c_dst,
+                                          long M, int C, int Cz) {
+  const long total = M * Cz;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cz);
+    const long m = i / Cz;
+    y[m * ldy + c_dst + c] = c < C ? x[m * ldx + c_src + c] : from_f32<T>(0.f);
+  }
+}
+
 // nn.Softplus(beta=1, threshold=20): adaptive_scaling.py:101,140
 __global__ void softplus_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -407,6 +422,21 @@ extern "C" int vkas_copy_channels(const void* x, long ldx, void* y, long ldy, lo
                                                                                   Cp / 8, accumulate);
   })
   VKAS_LAUNCH_CHECK("copy_channels");
+  return VKAS_OK;
+}
+
+extern "C" int vkas_copy_channel_range(const void* x, long ldx, int c_src, void* y, long ldy, int c_dst, long M, int C,
+                                       int zero_tail, int dtype, void* stream) {
+  VKAS_CHECK(x && y, "vkas_copy_channel_range: null pointer");
+  VKAS_CHECK(C > 0 && zero_tail >= 0 && c_src >= 0 && c_dst >= 0 && ldx >= c_src + C && ldy >= c_dst + C + zero_tail,
+             "vkas_copy_channel_range: channel range [%d, %d) / [%d, %d) outside the pixel strides %ld / %ld", c_src, c_src + C,
+             c_dst, c_dst + C + zero_tail, ldx, ldy);
+  if (M <= 0) return VKAS_OK;
+  VKAS_DISPATCH_DTYPE(dtype, "vkas_copy_channel_range", {
+    copy_channel_range_kernel<T><<<grid1d(M * (C + zero_tail)), 256, 0, vkas_stream(stream)>>>(
+        (const T*)x, ldx, c_src, (T*)y, ldy, c_dst, M, C, C + zero_tail);
+  })
+  VKAS_LAUNCH_CHECK("copy_channel_range");
   return VKAS_OK;
 }
 

@@ -28,8 +28,8 @@ class AdaptiveScalingInferencingConfig:
     """inferencing/adaptive_scaling.py:41-58 (tensor-side fields, same names - including the reference's spelling
     ``legnth`` - and defaults).  ``model_jit``: the path of a TorchScript file (the reference's usage) or of a state-dict
     file (then ``model_config`` is needed), a scripted module, or an eager ``AdaptiveScaling`` module - which is then
-    switched to eval mode and to ``compute_dtype`` IN PLACE (pass a copy to keep a training module as it is); a scripted
-    module runs in the storage type it was scripted with."""
+    switched to eval mode and to ``compute_dtype`` IN PLACE (pass a copy to keep a training module as it is), a scripted one
+    likewise (its recipe string is rewritten)."""
     model_jit: Union[str, AdaptiveScaling, torch.jit.ScriptModule, None] = None
     device: str = 'cuda'
     backbone_downsampling_factor: int = 32
@@ -103,6 +103,12 @@ class AdaptiveScalingInferencing:
                 module.load_state_dict(sd)
                 model = module
         if isinstance(model, torch.jit.ScriptModule):
+            # a scripted module carries its construction recipe as a string attribute (model/scripting.py); the storage type
+            # in it is switched to config.compute_dtype, as set_compute_dtype does for an eager module below
+            from ..model import scripting
+            if not hasattr(model, '_script_spec'):
+                raise TypeError('config.model_jit is a TorchScript module that this package did not script')
+            model._script_spec = scripting.with_compute_dtype(model._script_spec, config.compute_dtype)
             self.model = model.to(config.device).eval()
             return
         if not isinstance(model, AdaptiveScaling):

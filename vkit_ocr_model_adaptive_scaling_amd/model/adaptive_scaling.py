@@ -110,7 +110,6 @@ class AdaptiveScaling(nn.Module):
         self._script_params = [p for _, p in self.named_parameters()]
         self._script_spec = ''
         set_compute_dtype(self, compute_dtype)
-        scripting.register_live(self)
 
     def set_compute_dtype(self, dtype: torch.dtype):
         return set_compute_dtype(self, dtype)

@@ -9,12 +9,14 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 from torch import nn
 
-from . import helper
+from . import helper, scripting
 from .. import ops
 
 
 class ConvNextBlockLayer(nn.Module):
     """convnext.py:20-59"""
+    _script_params: List[torch.Tensor]  # what the compiled forward hands to vkas::module_forward (model/scripting.py)
+    _script_spec: str
 
     def __init__(self, in_channels: int, prob_bypass: float = 0.0) -> None:
         super().__init__()
@@ -30,6 +32,10 @@ class ConvNextBlockLayer(nn.Module):
         self.block_scale = nn.Parameter(torch.full((in_channels, 1, 1), 1E-6))
         self.prob_bypass = prob_bypass
         self.compute_dtype = torch.bfloat16
+        scripting.init_script_state(self, {'in_channels': in_channels, 'prob_bypass': prob_bypass})
+
+    def _refresh_script_spec(self):
+        scripting.refresh_module_spec(self)
 
     def stochastic_depth_mask(self, batch: int, device) -> Optional[torch.Tensor]:
         """convnext.py:41-53: per-sample Bernoulli(keep) / keep in training mode, None otherwise."""
@@ -48,14 +54,27 @@ class ConvNextBlockLayer(nn.Module):
         return ops.ConvNextLayer.apply(x, dw.weight, dw.bias, norm.weight, norm.bias, fc1.weight, fc1.bias,
                                        fc2.weight, fc2.bias, self.block_scale, mask, torch.is_grad_enabled())
 
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """NCHW in, NCHW out (convnext.py:55-59); scripted: one call of vkas::module_forward (model/scripting.py)."""
+        if torch.jit.is_scripting():
+            return torch.ops.vkas.module_forward([x], self._script_params, self._script_spec, self.training)[0]
+        else:
+            return self._forward_eager(x)
+
     @torch.jit.unused
-    def forward(self, x: torch.Tensor) -> torch.Tensor:  # type: ignore
+    def _forward_eager(self, x: torch.Tensor) -> torch.Tensor:
         c = x.shape[1]
         return helper.act_to_nchw(self.forward_act(helper.nchw_to_act(x, self.compute_dtype)), c)
+
+    @torch.jit.unused
+    def _script_call(self, inputs: List[torch.Tensor]) -> List[torch.Tensor]:
+        return [self._forward_eager(inputs[0])]
 
 
 class ConvNextBlock(nn.Module):
     """convnext.py:62-101: N layers, an extra LayerNorm whose output is the emitted feature, optional 2x2/2 conv."""
+    _script_params: List[torch.Tensor]
+    _script_spec: str
 
     def __init__(self, layer_idx_begin: int, layer_idx_end: int, in_channels: int, num_layers: int,
                  out_channels: Optional[int]) -> None:
@@ -69,6 +88,12 @@ class ConvNextBlock(nn.Module):
         if out_channels:
             self.pconv2x2 = helper.pconv2x2(in_channels, out_channels)
         self.compute_dtype = torch.bfloat16
+        scripting.init_script_state(self, {'layer_idx_begin': layer_idx_begin, 'layer_idx_end': layer_idx_end,
+                                           'in_channels': in_channels, 'num_layers': num_layers,
+                                           'out_channels': out_channels})
+
+    def _refresh_script_spec(self):
+        scripting.refresh_module_spec(self)
 
     def forward_act(self, x: torch.Tensor, masks: Optional[Sequence[Optional[torch.Tensor]]] = None):
         for i, layer in enumerate(self.layers):
@@ -79,16 +104,30 @@ class ConvNextBlock(nn.Module):
             x = ops.Conv.apply(feature, self.pconv2x2.weight, self.pconv2x2.bias, 2, 0)
         return feature, x
 
+    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """convnext.py:93-101: (emitted feature, input of the next stage), NCHW."""
+        if torch.jit.is_scripting():
+            outs = torch.ops.vkas.module_forward([x], self._script_params, self._script_spec, self.training)
+            return outs[0], outs[1]
+        else:
+            return self._forward_eager(x)
+
     @torch.jit.unused
-    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:  # type: ignore
+    def _forward_eager(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         c = x.shape[1]
         feature, y = self.forward_act(helper.nchw_to_act(x, self.compute_dtype))
         c_out = self.pconv2x2.out_channels if self.pconv2x2 is not None else c
         return helper.act_to_nchw(feature, c), helper.act_to_nchw(y, c_out)
 
+    @torch.jit.unused
+    def _script_call(self, inputs: List[torch.Tensor]) -> List[torch.Tensor]:
+        return list(self._forward_eager(inputs[0]))
+
 
 class ConvNext(nn.Module):
     """convnext.py:104-235"""
+    _script_params: List[torch.Tensor]
+    _script_spec: str
 
     @classmethod
     def build_stem(cls, stem_in_channels: int, block_in_channels: int, use_pconv2x2: bool):
@@ -121,6 +160,13 @@ class ConvNext(nn.Module):
                 nn.init.trunc_normal_(module.weight, std=0.02)
                 if module.bias is not None:
                     nn.init.zeros_(module.bias)
+        scripting.init_script_state(self, {'stem_in_channels': stem_in_channels,
+                                           'block_in_channels_and_num_layers':
+                                               [[int(c), int(n)] for c, n in block_in_channels_and_num_layers],
+                                           'stem_use_pconv2x2': bool(stem_use_pconv2x2)})
+
+    def _refresh_script_spec(self):
+        scripting.refresh_module_spec(self)
 
     @classmethod
     def create_tiny(cls, stem_use_pconv2x2: bool = False):
@@ -178,7 +224,19 @@ class ConvNext(nn.Module):
             feats.append(feature)
         return feats
 
+    def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
+        """convnext.py:216-235: (B,3,H,W) -> the four stage features, NCHW.  Scripted (tests/test_convnext.py:53-63 scripts
+        and calls the backbone on its own): one call of vkas::module_forward (model/scripting.py)."""
+        if torch.jit.is_scripting():
+            return torch.ops.vkas.module_forward([x], self._script_params, self._script_spec, self.training)
+        else:
+            return self._forward_eager(x)
+
     @torch.jit.unused
-    def forward(self, x: torch.Tensor) -> List[torch.Tensor]:  # type: ignore
+    def _forward_eager(self, x: torch.Tensor) -> List[torch.Tensor]:
         feats = self.forward_act(x)
         return [helper.act_to_nchw(f, c) for f, c in zip(feats, self.in_channels_group)]
+
+    @torch.jit.unused
+    def _script_call(self, inputs: List[torch.Tensor]) -> List[torch.Tensor]:
+        return self._forward_eager(inputs[0])

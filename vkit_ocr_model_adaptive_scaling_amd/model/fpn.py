@@ -4,7 +4,7 @@ from typing import List, Optional, Sequence
 import torch
 from torch import nn
 
-from . import helper
+from . import helper, scripting
 from .. import ops
 
 NEAREST = 1
@@ -33,6 +33,8 @@ def _init_kaiming(module: nn.Module):
 class FpnNeck(nn.Module):
     """fpn.py:51-146: 1x1 laterals to out_channels, top-down nearest add, 3x3 blocks to out/levels, nearest to
     level 0, concat."""
+    _script_params: List[torch.Tensor]  # what the compiled forward hands to vkas::module_forward (model/scripting.py)
+    _script_spec: str
 
     @classmethod
     def build_step1_conv_blocks(cls, in_channels_group: Sequence[int], out_channels: int):
@@ -47,13 +49,18 @@ class FpnNeck(nn.Module):
     def __init__(self, in_channels_group: Sequence[int], out_channels: int) -> None:
         super().__init__()
         assert len(in_channels_group) > 1
-        if out_channels % (8 * len(in_channels_group)) != 0:
-            raise NotImplementedError('HIP neck needs out_channels / levels to be a multiple of 8')
+        assert out_channels % len(in_channels_group) == 0  # fpn.py:75
         self.out_channels = out_channels
+        self.inner_channels = out_channels // len(in_channels_group)
         self.step1_conv_blocks = self.build_step1_conv_blocks(in_channels_group, out_channels)
         self.step2_conv_blocks = self.build_step2_conv_blocks(in_channels_group, out_channels)
         self.compute_dtype = torch.bfloat16
         _init_kaiming(self)
+        scripting.init_script_state(self, {'in_channels_group': [int(c) for c in in_channels_group],
+                                           'out_channels': out_channels})
+
+    def _refresh_script_spec(self):
+        scripting.refresh_module_spec(self)
 
     def forward_act(self, feats: Sequence[torch.Tensor]) -> torch.Tensor:
         n = len(feats)
@@ -62,16 +69,30 @@ class FpnNeck(nn.Module):
         for i in range(n - 1, 0, -1):
             outs[i - 1] = ops.ResizeAdd.apply(outs[i - 1], outs[i], NEAREST)
         outs = [helper.conv_block(o, blk[0], blk[2], 1, 1) for o, blk in zip(outs, self.step2_conv_blocks)]
-        return ops.ResizeCat.apply(NEAREST, *outs)  # every level resized to the finest one and concatenated (fpn.py:131-144)
+        # widths that are not multiples of 8 (e.g. out_channels = 400, tests/test_fpn.py:16-28) take ResizeCat's compact path
+        return ops.ResizeCat.apply(NEAREST, [self.inner_channels] * n, *outs)  # every level resized to the finest one and concatenated (fpn.py:131-144)
+
+    def forward(self, features: List[torch.Tensor]) -> torch.Tensor:
+        """fpn.py:110-146; scripted (tests/test_fpn.py:30): one call of vkas::module_forward."""
+        if torch.jit.is_scripting():
+            return torch.ops.vkas.module_forward(features, self._script_params, self._script_spec, self.training)[0]
+        else:
+            return self._forward_eager(features)
 
     @torch.jit.unused
-    def forward(self, features: List[torch.Tensor]) -> torch.Tensor:  # type: ignore
+    def _forward_eager(self, features: List[torch.Tensor]) -> torch.Tensor:
         acts = [helper.nchw_to_act(f, self.compute_dtype) for f in features]
         return helper.act_to_nchw(self.forward_act(acts), self.out_channels)
+
+    @torch.jit.unused
+    def _script_call(self, inputs: List[torch.Tensor]) -> List[torch.Tensor]:
+        return [self._forward_eager(inputs)]
 
 
 class FpnHead(nn.Module):
     """fpn.py:149-208"""
+    _script_params: List[torch.Tensor]
+    _script_spec: str
 
     def __init__(self, in_channels: int, out_channels: int, upsampling_factor: int = 1,
                  init_output_bias: float = 0.0):
@@ -90,6 +111,12 @@ class FpnHead(nn.Module):
         self.compute_dtype = torch.bfloat16
         _init_kaiming(self)
         nn.init.constant_(self.step2_conv[1].bias, init_output_bias)  # fpn.py:191
+        scripting.init_script_state(self, {'in_channels': in_channels, 'out_channels': out_channels,
+                                           'upsampling_factor': upsampling_factor,
+                                           'init_output_bias': float(init_output_bias)})
+
+    def _refresh_script_spec(self):
+        scripting.refresh_module_spec(self)
 
     def conv_norm_proj(self):
         """(3x3 conv, its LayerNorm, the 1x1 projection) parameter holders."""
@@ -108,6 +135,17 @@ class FpnHead(nn.Module):
         y = ops.Conv.apply(x, proj.weight, proj.bias, 1, 0)
         return ops.ToNchw.apply(y, self.out_channels)
 
+    def forward(self, fpn_neck_feature: torch.Tensor) -> torch.Tensor:
+        if torch.jit.is_scripting():
+            return torch.ops.vkas.module_forward([fpn_neck_feature], self._script_params, self._script_spec,
+                                                 self.training)[0]
+        else:
+            return self._forward_eager(fpn_neck_feature)
+
     @torch.jit.unused
-    def forward(self, fpn_neck_feature: torch.Tensor) -> torch.Tensor:  # type: ignore
+    def _forward_eager(self, fpn_neck_feature: torch.Tensor) -> torch.Tensor:
         return self.forward_act(helper.nchw_to_act(fpn_neck_feature, self.compute_dtype))
+
+    @torch.jit.unused
+    def _script_call(self, inputs: List[torch.Tensor]) -> List[torch.Tensor]:
+        return [self._forward_eager(inputs[0])]

@@ -4,7 +4,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 from torch import nn
 
-from . import helper
+from . import helper, scripting
 from .. import ops
 
 BILINEAR = 0
@@ -35,30 +35,51 @@ def _init_trunc_normal(module: nn.Module):
 
 class PpmBlock(nn.Module):
     """upernext.py:48-84: pooled 1x1 branches, bilinear back to the input size, concat, 3x3 block."""
+    _script_params: List[torch.Tensor]  # what the compiled forward hands to vkas::module_forward (model/scripting.py)
+    _script_spec: str
 
     def __init__(self, ppm_scales: Sequence[int], in_channels: int, out_channels: int) -> None:
         super().__init__()
         self.ppm_scales = tuple(ppm_scales)
+        self.in_channels, self.branch_channels = in_channels, out_channels
         self.ap_conv_blocks = nn.ModuleList([
             nn.Sequential(nn.AdaptiveAvgPool2d(s), build_conv1x1_block(in_channels, out_channels)) for s in ppm_scales
         ])
         self.final_conv_block = build_conv3x3_block(in_channels + len(ppm_scales) * out_channels, out_channels)
         self.compute_dtype = torch.bfloat16
+        scripting.init_script_state(self, {'ppm_scales': [int(v) for v in ppm_scales], 'in_channels': in_channels,
+                                           'out_channels': out_channels})
+
+    def _refresh_script_spec(self):
+        scripting.refresh_module_spec(self)
 
     def forward_act(self, x: torch.Tensor) -> torch.Tensor:
         pooled = ops.AdaptiveAvgPools.apply(x, *self.ppm_scales)  # one node: its backward sums the branches' gradients
         parts = [helper.conv_block(f, branch[1][1], branch[1][2]) for f, branch in zip(pooled, self.ap_conv_blocks)]
-        cat = ops.ResizeCat.apply(BILINEAR, x, *parts)  # the pooled branches resized to x and concatenated behind it
+        widths = [self.in_channels] + [self.branch_channels] * len(parts)
+        cat = ops.ResizeCat.apply(BILINEAR, widths, x, *parts)  # the pooled branches resized to x and concatenated behind it
         return helper.conv_block(cat, self.final_conv_block[0], self.final_conv_block[2], 1, 1)
 
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if torch.jit.is_scripting():
+            return torch.ops.vkas.module_forward([x], self._script_params, self._script_spec, self.training)[0]
+        else:
+            return self._forward_eager(x)
+
     @torch.jit.unused
-    def forward(self, x: torch.Tensor) -> torch.Tensor:  # type: ignore
+    def _forward_eager(self, x: torch.Tensor) -> torch.Tensor:
         out_c = self.final_conv_block[0].out_channels
         return helper.act_to_nchw(self.forward_act(helper.nchw_to_act(x, self.compute_dtype)), out_c)
+
+    @torch.jit.unused
+    def _script_call(self, inputs: List[torch.Tensor]) -> List[torch.Tensor]:
+        return [self._forward_eager(inputs[0])]
 
 
 class UperNextNeck(nn.Module):
     """upernext.py:87-198"""
+    _script_params: List[torch.Tensor]
+    _script_spec: str
 
     @classmethod
     def build_step1_conv_blocks(cls, in_channels_group: Sequence[int], ppm_scales: Sequence[int], inner_channels: int):
@@ -78,14 +99,17 @@ class UperNextNeck(nn.Module):
         assert len(in_channels_group) > 1
         assert out_channels % len(in_channels_group) == 0
         inner_channels = out_channels // len(in_channels_group)
-        if inner_channels % 8 != 0:
-            raise NotImplementedError('HIP neck needs out_channels / levels to be a multiple of 8')
         self.inner_channels = inner_channels
         self.out_channels = out_channels
         self.step1_conv_blocks = self.build_step1_conv_blocks(in_channels_group, ppm_scales, inner_channels)
         self.step2_conv_blocks = self.build_step2_conv_blocks(len(self.step1_conv_blocks), inner_channels)
         self.compute_dtype = torch.bfloat16
         _init_trunc_normal(self)
+        scripting.init_script_state(self, {'in_channels_group': [int(c) for c in in_channels_group],
+                                           'out_channels': out_channels, 'ppm_scales': [int(v) for v in ppm_scales]})
+
+    def _refresh_script_spec(self):
+        scripting.refresh_module_spec(self)
 
     def forward_act(self, feats: Sequence[torch.Tensor]) -> torch.Tensor:
         n = len(feats)
@@ -99,16 +123,29 @@ class UperNextNeck(nn.Module):
             outs[i] = helper.conv_block(outs[i], blk[0], blk[2], 1, 1)
         # every level resized to the finest one and concatenated (upernext.py:184-197): one op, the resize kernels write
         # into their channel slices
-        return ops.ResizeCat.apply(BILINEAR, *outs)
+        return ops.ResizeCat.apply(BILINEAR, [self.inner_channels] * n, *outs)
+
+    def forward(self, features: List[torch.Tensor]) -> torch.Tensor:
+        """upernext.py:163-198: the backbone's NCHW features -> (B, out_channels, H/4, W/4)."""
+        if torch.jit.is_scripting():
+            return torch.ops.vkas.module_forward(features, self._script_params, self._script_spec, self.training)[0]
+        else:
+            return self._forward_eager(features)
 
     @torch.jit.unused
-    def forward(self, features: List[torch.Tensor]) -> torch.Tensor:  # type: ignore
+    def _forward_eager(self, features: List[torch.Tensor]) -> torch.Tensor:
         acts = [helper.nchw_to_act(f, self.compute_dtype) for f in features]
         return helper.act_to_nchw(self.forward_act(acts), self.out_channels)
+
+    @torch.jit.unused
+    def _script_call(self, inputs: List[torch.Tensor]) -> List[torch.Tensor]:
+        return [self._forward_eager(inputs)]
 
 
 class UperNextHead(nn.Module):
     """upernext.py:201-248: x`factor` bilinear -> 3x3 block to (in+out)//2 -> Linear to out_channels."""
+    _script_params: List[torch.Tensor]
+    _script_spec: str
 
     def __init__(self, in_channels: int, out_channels: int, upsampling_factor: int = 1,
                  init_output_bias: float = 0.0):
@@ -122,6 +159,12 @@ class UperNextHead(nn.Module):
         self.compute_dtype = torch.bfloat16
         _init_trunc_normal(self)
         nn.init.constant_(self.step2_conv1x1[1].bias, init_output_bias)  # upernext.py:231
+        scripting.init_script_state(self, {'in_channels': in_channels, 'out_channels': out_channels,
+                                           'upsampling_factor': upsampling_factor,
+                                           'init_output_bias': float(init_output_bias)})
+
+    def _refresh_script_spec(self):
+        scripting.refresh_module_spec(self)
 
     def conv_norm_proj(self):
         """(3x3 conv, its LayerNorm, the 1x1 projection) parameter holders."""
@@ -142,6 +185,17 @@ class UperNextHead(nn.Module):
         y = ops.Conv.apply(x, proj.weight, proj.bias, 1, 0)
         return ops.ToNchw.apply(y, self.out_channels)
 
+    def forward(self, fpn_neck_feature: torch.Tensor) -> torch.Tensor:
+        if torch.jit.is_scripting():
+            return torch.ops.vkas.module_forward([fpn_neck_feature], self._script_params, self._script_spec,
+                                                 self.training)[0]
+        else:
+            return self._forward_eager(fpn_neck_feature)
+
     @torch.jit.unused
-    def forward(self, fpn_neck_feature: torch.Tensor) -> torch.Tensor:  # type: ignore
+    def _forward_eager(self, fpn_neck_feature: torch.Tensor) -> torch.Tensor:
         return self.forward_act(helper.nchw_to_act(fpn_neck_feature, self.compute_dtype))
+
+    @torch.jit.unused
+    def _script_call(self, inputs: List[torch.Tensor]) -> List[torch.Tensor]:
+        return [self._forward_eager(inputs[0])]

@@ -512,7 +512,9 @@ def conv_param_grads(x, geom, dy, Np: int, weight: torch.Tensor, bias: Optional[
         gw = unpack_wgrad(gwp, (N, C, KH, KW), Np, Cp).view(weight.shape)
     gb = None
     if bias is not None and gb_into is None:
-        gb = gbp[:N]
+        # a slice of the step's zero arena must not reach autograd: AccumulateGrad ADOPTS an incoming tensor when the
+        # parameter's .grad is None (set_to_none), and the next arena reset would zero the adopted gradient
+        gb = gbp[:N].clone() if scratch else gbp[:N]
     if sw is not None:
         sw[0].grad_delivered(sw[1])
     if gb_into is not None:
@@ -1087,7 +1089,8 @@ class HeadsFused(Function):
             for param, g, rows in per:
                 sk = grad_sink(param)
                 if sk is None or not param.grad.is_contiguous():
-                    out.append(g)
+                    # handed to autograd: never a view of the step's zero arena (see conv_param_grads)
+                    out.append(g.clone() if (flat_sinks and g is gbs[h]) else g)
                     continue
                 off = 0
                 for src, so, cnt in rows:
@@ -1587,37 +1590,75 @@ class Cat(Function):
         return tuple(outs)
 
 
+def copy_channel_range(x, c_src: int, out, c_dst: int, C: int, zero_tail: int = 0):
+    """out[..., c_dst : c_dst + C] = x[..., c_src : c_src + C] (then ``zero_tail`` zero channels): channel offsets at
+    element granularity, for concatenations whose parts are not multiples of 8 channels wide."""
+    B, H, W, _ = x.shape
+    check(lib.vkas_copy_channel_range(_p(x), act_ld(x), c_src, _p(out), act_ld(out), c_dst, B * H * W, C, zero_tail, _dt(x),
+                                      _stream()), 'copy_channel_range')
+    return out
+
+
 class ResizeCat(Function):
     """torch.cat([first] + [F.interpolate(p, first's size) for p in others], channels) (model/upernext.py:184-197): the
     resize kernels write straight into their channel slice of the concatenated buffer, so only ``first`` is copied; backward
-    reads each slice of the incoming gradient in place."""
+    reads each slice of the incoming gradient in place.
+
+    ``widths``: the parts' LOGICAL channel counts, or None when every part is as wide as its activation.  The reference
+    only asks for ``out_channels % len(levels) == 0`` (upernext.py:144, fpn.py:75) and its own test builds
+    ``FpnNeck(..., out_channels=400)`` = 4 x 100 channels (tests/test_fpn.py:16-28): torch.cat puts the parts side by side
+    WITHOUT pad channels, so part i starts at channel 100 i - not a 16-byte boundary.  Such a concatenation takes the
+    compact path: every part is resized into a buffer of its own and moved to its element-granular channel offset by
+    vkas_copy_channel_range; backward cuts the gradient's slices out into zero-padded buffers the same way."""
 
     @staticmethod
-    def forward(ctx, mode: int, first, *others):
+    def forward(ctx, mode: int, widths, first, *others):
         _require_cuda(first, *others)
         first = as_act(first)
         others = [as_act(p) for p in others]
         B, H, W, w0 = first.shape
-        widths = [w0] + [p.shape[3] for p in others]
-        out = new_act(B, H, W, sum(widths), first)
-        copy_channels(first, out[..., :w0])
-        off = w0
-        for p in others:
-            resize_fwd(p, (H, W), mode, out=out[..., off:off + p.shape[3]])
-            off += p.shape[3]
+        padded = [w0] + [p.shape[3] for p in others]
+        widths = padded if widths is None else [int(w) for w in widths]
+        if len(widths) != len(padded) or any(rup8(w) != pw for w, pw in zip(widths, padded)):
+            raise ValueError(f'ResizeCat: logical widths {widths} do not match the activations\' channels {padded}')
         ctx.cfg = (mode, widths, [(p.shape[1], p.shape[2]) for p in others])
+        if all(w % 8 == 0 for w in widths):
+            out = new_act(B, H, W, sum(widths), first)
+            copy_channels(first, out[..., :w0])
+            off = w0
+            for p in others:
+                resize_fwd(p, (H, W), mode, out=out[..., off:off + p.shape[3]])
+                off += p.shape[3]
+            return out
+        total = sum(widths)
+        out = new_act(B, H, W, rup8(total), first)
+        off = 0
+        for i, (p, w) in enumerate(zip([first] + others, widths)):
+            r = p if i == 0 else resize_fwd(p, (H, W), mode)
+            last = i == len(widths) - 1
+            copy_channel_range(r, 0, out, off, w, (rup8(total) - total) if last else 0)
+            off += w
         return out
 
     @staticmethod
     def backward(ctx, dy):
         mode, widths, in_sizes = ctx.cfg
         dy = as_act(dy)
-        grads = [dy[..., :widths[0]]]
-        off = widths[0]
-        for w, size in zip(widths[1:], in_sizes):
-            grads.append(resize_bwd(dy[..., off:off + w], size, mode))
+        if all(w % 8 == 0 for w in widths):
+            grads = [dy[..., :widths[0]]]
+            off = widths[0]
+            for w, size in zip(widths[1:], in_sizes):
+                grads.append(resize_bwd(dy[..., off:off + w], size, mode))
+                off += w
+            return (None, None, *grads)
+        B, H, W, _ = dy.shape
+        grads, off = [], 0
+        for i, w in enumerate(widths):
+            g = new_act(B, H, W, rup8(w), dy)
+            copy_channel_range(dy, off, g, 0, w, rup8(w) - w)  # pad channels of an activation gradient are zero
+            grads.append(g if i == 0 else resize_bwd(g, in_sizes[i - 1], mode))
             off += w
-        return (None, *grads)
+        return (None, None, *grads)
 
 
 class SplitBatch(Function):

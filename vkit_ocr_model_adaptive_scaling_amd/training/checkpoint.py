@@ -33,17 +33,18 @@ def optimizer_state_dict(optimizer) -> Dict[str, Any]:
     state = {}
     if optimizer.step_count > 0:
         # one copy of each moment buffer to the host, sliced there.  torch.optim.AdamW holds no state for a parameter that never
-        # received a gradient (the fused step skips those too: precise_char_mask_head when disabled, ...); such a parameter's
-        # second moment is still exactly zero everywhere, which is how it is told apart here
+        # received a gradient (the fused step skips those too: a head that a pass never runs, ...) and full state - step N, zero
+        # moments - for one whose gradients were exactly zero: FlatAdamW.has_state records which parameters a step has updated
         m1, m2 = optimizer.exp_avg.detach().cpu(), optimizer.exp_avg_sq.detach().cpu()
+        has_state = getattr(optimizer, 'has_state', None)  # an optimizer object without the record: every parameter has state
         for i, n in enumerate(flat.names):
+            if has_state is not None and not has_state[i]:
+                continue
             start, size = flat.offsets[n]
             shape = flat.params[i].shape
-            v = m2[start:start + size]
-            if not bool(v.any()):
-                continue
             state[i] = {'step': torch.tensor(float(optimizer.step_count)),
-                        'exp_avg': m1[start:start + size].view(shape).clone(), 'exp_avg_sq': v.view(shape).clone()}
+                        'exp_avg': m1[start:start + size].view(shape).clone(),
+                        'exp_avg_sq': m2[start:start + size].view(shape).clone()}
     group = {'lr': optimizer.lr, 'betas': tuple(optimizer.betas), 'eps': optimizer.eps, 'weight_decay': optimizer.weight_decay,
              'amsgrad': False, 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
              'initial_lr': optimizer.lr, 'params': list(range(len(flat.names)))}
@@ -63,11 +64,14 @@ def load_optimizer_state_dict(optimizer, sd: Mapping[str, Any]):
     optimizer.exp_avg.zero_()
     optimizer.exp_avg_sq.zero_()
     step = 0
+    optimizer.has_state = bytearray(len(flat.names))
+    optimizer.restored_from_state = True
     with torch.no_grad():
         for i, pid in enumerate(group['params']):
             st = sd['state'].get(pid)
             if st is None:
                 continue
+            optimizer.has_state[i] = 1
             start, size = flat.offsets[flat.names[i]]
             if st['exp_avg'].numel() != size:
                 raise ValueError(f'moment shape mismatch for {flat.names[i]}')

@@ -13,6 +13,7 @@ are ``torch.distributed.all_reduce(..., async_op=True)`` on slices of the flat b
 is RCCL over xGMI on its own stream, ordered after the compute stream at launch and joined by ``wait()`` before the
 clip + AdamW kernels.  Gradients are averaged by pre-scaling the losses with 1/world_size.  Works with ``gloo`` on CPU
 tensors as well (tests)."""
+import os
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -33,10 +34,18 @@ class Bucket:
 class BucketedGradReducer:
 
     def __init__(self, flat: FlatBuffers, bucket_prefixes: Sequence[Tuple[str, Tuple[str, ...]]],
-                 process_group=None):
+                 process_group=None, always_reduce: Optional[bool] = None):
+        """always_reduce (default: environment VKAS_FORCE_REDUCER=1): issue the collectives at world size 1 as well (a sum
+        over one rank leaves the gradient as it is).  A test / measurement switch: it runs the whole N > 1 code path - RCCL
+        library load, communicator, the side stream's ordering against the compute stream, all_reduce launched from a callback
+        inside autograd's backward thread, wait() before the clip kernel - on the one GPU a build box has."""
         self.flat = flat
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if always_reduce is None:
+            always_reduce = os.environ.get('VKAS_FORCE_REDUCER', '0') == '1'
+        self.collective = self.world_size > 1 or (bool(always_reduce) and dist.is_initialized())
+        self.collectives_issued = 0
         self.buckets: Dict[str, Bucket] = {}
         self._param_bucket: Dict[str, Bucket] = {}
         covered = set()
@@ -83,8 +92,9 @@ class BucketedGradReducer:
 
     def _launch(self, b: Bucket):
         self.launch_log.append(b.name)
-        if self.world_size == 1:
+        if not self.collective:
             return
+        self.collectives_issued += 1
         work = dist.all_reduce(self.flat.flat_grad[b.start:b.end], op=dist.ReduceOp.SUM, group=self.group,
                                async_op=True)
         self._works.append(work)

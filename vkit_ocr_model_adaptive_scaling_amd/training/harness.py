@@ -109,8 +109,13 @@ def run_training(step, train_batches_of_epoch: Callable[[int], Iterable[Dict]], 
     oc, ec = optimizer_config, epoch_config
     # the optimizer hyper-parameters of the run are those of its config record (train.py:287-298): applied here so that the
     # JSON written next to the checkpoints cannot disagree with what trained
+    # ... unless the optimizer was restored from a RestoreState file: the reference constructs AdamW from the config and then
+    # calls optimizer.load_state_dict (train.py:287-322), so a resumed run trains with the CHECKPOINT's betas / weight decay and
+    # only the learning-rate pair is patched from the config; the clip norm is no optimizer state and always the config's
     opt = step.optimizer
-    opt.betas, opt.weight_decay, opt.max_grad_norm = tuple(oc.adamw_betas), oc.adamw_weight_decay, oc.clip_grad_norm_max_norm
+    if not getattr(opt, 'restored_from_state', False):
+        opt.betas, opt.weight_decay = tuple(oc.adamw_betas), oc.adamw_weight_decay
+    opt.max_grad_norm = oc.clip_grad_norm_max_norm
     world = getattr(step, 'world', 1)
     rank = torch.distributed.get_rank() if (world > 1 and torch.distributed.is_initialized()) else 0
 

@@ -54,6 +54,12 @@ class FlatAdamW:
         self.exp_avg_sq = torch.zeros_like(flat.flat_param)
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=flat.flat_param.device)
         self.step_count = 0
+        # which parameters hold optimizer state, i.e. were updated by some step so far: torch.optim.AdamW creates a parameter's
+        # state at its first step with a gradient (an exactly-zero gradient included) and never for a parameter whose .grad
+        # stayed None; the RestoreState export goes by this record (training/checkpoint.py)
+        self.has_state = bytearray(len(flat.params))
+        # hyper-parameters restored from a checkpoint win over a config record on resume (training/harness.py)
+        self.restored_from_state = False
 
     def zero_grad(self):
         self.flat.zero_grad()
@@ -71,7 +77,11 @@ class FlatAdamW:
         # precise mask head under precise_enable_char_mask_head, which forward_precise never runs.  One launch per
         # contiguous run of parameters that did receive a gradient (normally the whole buffer).
         # (no hook fired at all = the gradients were written into the flat buffer by hand: update everything)
-        ranges = f.touched_ranges() if all_or_none(f.touched) is None else [(0, f.numel)]
+        partial = all_or_none(f.touched) is None
+        ranges = f.touched_ranges() if partial else [(0, f.numel)]
+        for i in range(len(self.has_state)):
+            if not partial or f.touched[i]:
+                self.has_state[i] = 1
         for start, end in ranges:
             off = lambda t: ctypes.c_void_p(t.data_ptr() + 4 * start)
             check(lib.vkas_adamw_step(off(f.flat_param), off(f.flat_grad), off(self.exp_avg), off(self.exp_avg_sq),
