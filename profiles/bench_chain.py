@@ -21,7 +21,7 @@ def ptr(t):
     return None if t is None else P(t.data_ptr())
 
 
-def run(path, M, C, keep=None):
+def run(path, M, C, keep=None, only=None):
     lib = ctypes.CDLL(path)
     lib.vkas_mlp_chain_image_elems.restype = ctypes.c_size_t
     lib.vkas_mlp_chain_image_elems.argtypes = [ctypes.c_int]
@@ -64,6 +64,8 @@ def run(path, M, C, keep=None):
 
     res = {}
     for name, fn, nbytes in (('fwd', fwd, M * (4 * C + H4) * 2), ('bwd', bwd, M * (2 * C + 2 * H4) * 2)):
+        if only is not None and name != only:
+            continue
         fn()
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -83,8 +85,12 @@ def run(path, M, C, keep=None):
 
 
 def main():
-    libs = sys.argv[1:] or [os.path.join(ROOT, 'vkit_ocr_model_adaptive_scaling_amd', 'libvkas.so')]
-    for M, C in ((1048576, 96), (262144, 192), (1048576 + 40, 96)):
+    libs = [a for a in sys.argv[1:] if not a.startswith('--')] or [os.path.join(ROOT, 'vkit_ocr_model_adaptive_scaling_amd', 'libvkas.so')]
+    shapes = ((1048576, 96), (262144, 192), (1048576 + 40, 96))
+    for a in sys.argv[1:]:  # --shapes=65536x384,16384x384  (VKAS_CHAIN_PAIR=0 in the environment: the one-wave-per-SIMD kernel at C > 256)
+        if a.startswith('--shapes='):
+            shapes = tuple(tuple(int(v) for v in sh.split('x')) for sh in a[9:].split(','))
+    for M, C in shapes:
         keep = None
         for p in libs:
             o = run(p, M, C, keep)

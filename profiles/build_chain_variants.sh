@@ -9,10 +9,16 @@ for abl in "$@"; do
   for f in *.hip; do
     o=build/${f%.hip}.o
     if [ "$f" = mlp_chain.hip ]; then
-      o=../../build_variants/mlp_chain_abl$abl.o
-      hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-value -DCHAIN_ABL=$abl -c $f -o $o
+      o=../../build_variants/mlp_chain_abl${abl//[=,]/_}.o
+      # "trace": phase timestamps (profiles/trace_chain.py); NAME=VALUE[,NAME=VALUE]: -DNAME=VALUE ...; a number: -DCHAIN_ABL=<mask>
+      case "$abl" in
+        trace) def="-DCHAIN_TRACE" ;;
+        *=*) def="-D${abl//,/ -D}" ;;
+        *) def="-DCHAIN_ABL=$abl" ;;
+      esac
+      hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-value $def -c $f -o $o
     fi
     objs="$objs $o"
   done
-  hipcc --offload-arch=gfx950 -shared -fPIC $objs -o ../../build_variants/libvkas_chain$abl.so
+  hipcc --offload-arch=gfx950 -shared -fPIC $objs build/gemm_mfma_f16.o -o ../../build_variants/libvkas_chain${abl//[=,]/_}.so
 done

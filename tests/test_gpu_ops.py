@@ -218,7 +218,7 @@ def test_convnext_layer(shape, dtype):
     assert r < gtol, ('dx', r)
 
 
-@pytest.mark.parametrize('C', [16, 96, 192, 384, 512])
+@pytest.mark.parametrize('C', [16, 96, 192, 320, 384, 512])
 def test_mlp_chain_matches_two_gemm_path(C):
     """The fused MLP kernels against the two-GEMM layer path they replace (same bf16 inputs; the two differ only in
     where fp32 values are rounded to bf16): outputs and every gradient, ragged M (not a multiple of the 256/128-row tile),

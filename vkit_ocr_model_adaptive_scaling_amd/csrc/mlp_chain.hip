@@ -19,6 +19,10 @@
 //    (buffer_load_dwordx4 ... lds), double buffered, one barrier per chunk.  All workgroups stream the same
 //    147 KB - 1 MB of weights from L2.
 //  * 256 threads, two workgroups per CU: one workgroup's epilogue / prologue overlaps the other's main loop.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "vkas_common.h"
 
 namespace {
@@ -28,7 +32,8 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 constexpr int MODE_FWD = 0, MODE_BWD = 1;
 
 // Timing-only ablation switches for profiles/bench_chain.py (never set in the shipped build; results are wrong when set):
-// 1 no h / dh stores, 2 no epilogue traffic, 4 no GELU arithmetic, 8 no h loads (backward).
+// 1 no h / dh stores, 2 no epilogue traffic, 4 no GELU arithmetic, 8 no h loads (backward); pair kernel only: 16 no weight
+// requests inside the loop, 32 one fragment read per MFMA phase.
 #ifndef CHAIN_ABL
 #define CHAIN_ABL 0
 #endif
@@ -151,15 +156,27 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
   const int n_img = (NI - wave + 3) / 4;      // image DMA instructions this wave issues per chunk (q*4 + wave < NI)
   constexpr unsigned OOB = 0xFFFFFFF0u;
 
+  // LDS-DMA through vkas_lds_dma16 (vkas_common.h), not the compiler's builtin: with the builtin SIInsertWaitcnts put an
+  // s_waitcnt vmcnt(0) in front of the first LDS read it considered aliasing (the fp32 bias read of the image), i.e. the
+  // "prefetched" next chunk was waited for at the top of every chunk (round 4, profiles/isa_loops.py)
+#ifdef CHAIN_BUILTIN_DMA
   const __amdgpu_buffer_rsrc_t rs_w =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.img, (short)0, (int)((long)nchunks * IMG * 2), 0x00020000);
+#else
+  const u32x4 rs_w = vkas_make_rsrc(p.img, (unsigned)((long)nchunks * IMG * 2));
+  const unsigned lds0 = vkas_lds_addr(lds);
+#endif
   auto issue_chunk = [&](int j, int buf) {
 #pragma unroll
     for (int q = 0; q < (NI + 3) / 4; ++q) {
       const int inst = q * 4 + wave;
       if (inst >= NI) break;  // wave-uniform
       const unsigned voff = (unsigned)j * (unsigned)(IMG * 2) + (unsigned)inst * 1024u + (unsigned)lane * 16u;
+#ifdef CHAIN_BUILTIN_DMA
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_ptr)((lds_T*)lds + buf * IMG + inst * 512), 16, voff, 0, 0, 0);
+#else
+      vkas_lds_dma16(rs_w, lds0 + (unsigned)(buf * IMG + inst * 512) * 2u, voff);
+#endif
     }
   };
   issue_chunk(0, 0);
@@ -171,9 +188,14 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
   auto stg_off = [&](int r, int e) { return r * 64 + ((((e >> 3) ^ (r >> 1)) & 7) << 3) + (e & 7); };
   const int f_r = lane >> 3, f_pp = lane & 7;  // flush / DMA role: row f_r of a piece, position f_pp
   // backward: saved pre-activations of chunk pair P -> staging buffer (LDS-DMA, whole 128-byte row pieces)
+#ifdef CHAIN_BUILTIN_DMA
   __amdgpu_buffer_rsrc_t rs_h;
   if constexpr (MODE == MODE_BWD)
     rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)p.mid_in, (short)0, (int)(((p.M - 1) * p.ldmi + p.HID) * 2), 0x00020000);
+#else
+  u32x4 rs_h = {0, 0, 0, 0};
+  if constexpr (MODE == MODE_BWD) rs_h = vkas_make_rsrc(p.mid_in, (unsigned)(((p.M - 1) * p.ldmi + p.HID) * 2));
+#endif
   auto issue_h = [&](int P) {
 #pragma unroll
     for (int it = 0; it < NF; ++it) {
@@ -182,7 +204,11 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
       const long m = row0 + r;
       const bool ok = m < p.M && P * 64 + c * 8 < p.HID && !(ABL & 8);
       const unsigned voff = ok ? (unsigned)((m * p.ldmi + P * 64 + c * 8) * 2) : OOB;
+#ifdef CHAIN_BUILTIN_DMA
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (lds_void_ptr)((lds_T*)stg + it * 512), 16, voff, 0, 0, 0);
+#else
+      vkas_lds_dma16(rs_h, vkas_lds_addr(stg) + (unsigned)(it * 1024), voff);
+#endif
     }
   };
   // staged pair -> global (h forward, dh backward): 8 rows x 128 B per instruction, whole cache lines
@@ -442,11 +468,432 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Pair-split chain for 256 < C <= 384 (stage 2 of ConvNeXt-T / -S: 9 / 27 of the backbone's layers), round 4.
+//
+// At C = 384 the kernel above needs 192 accumulator + 96 input registers per wave, i.e. one 512-register wave per SIMD:
+// nothing overlaps its GELU arithmetic, LDS fragment latency and staging with the matrix pipe, and it measured no faster than
+// the two GEMMs it replaces (0.31 ms per layer and direction).  This variant keeps the chain's data flow but splits a
+// 32-row group over a PAIR of waves so that a wave fits 256 registers and every SIMD holds two waves:
+//   * wave t (0 / 1) of a pair computes GEMM-a for hidden units 16 t .. 16 t + 15 of every 32-unit chunk (its 32 input rows
+//     stay in registers as B fragments: 96 registers) and GEMM-b for output columns 192 t .. 192 t + 191 (96 accumulator
+//     registers).  GEMM-b's K = 32 fragment needs both halves of the chunk's activation: each wave hands its 4 values per
+//     lane and row group to its partner through LDS (8 bytes per lane: the D layout of GEMM-a IS the B layout of GEMM-b under
+//     the k permutation baked into the weight image, so the exchange is lane to lane).  No product is computed twice.
+//   * 8 waves = 4 pairs = 128 rows per workgroup; the two wave groups (waves 0-3 / 4-7: one wave of each on every SIMD) run
+//     half an iteration apart, as in conv3x3_slab_mfma_kernel: per chunk a wave has an MFMA phase (GEMM-b of the previous
+//     chunk, GEMM-a of this one: 48 MFMAs, 24 fragment reads) and a VALU phase (bias, rounding, GELU, staging, exchange,
+//     LDS-DMA requests), each closed by a barrier; while one group multiplies the other one does its vector work.
+//   * weights: the packed chunk images of the kernel above, unchanged; GEMM-a tiles and GEMM-b tiles in two rings of two slots
+//     (a slot is refilled by LDS-DMA as soon as both groups have read it, one and a half to two intervals before its next use).
+// LDS: 2 x 24 KB + 2 x 24 KB weight rings, 32 KB staging of the 4C-wide tensor (128-byte row pieces, per pair, two chunk
+// pairs), 16 KB exchange, bias pieces: 145 KB.
+// Phase timestamps of mlp_chain_pair_kernel for profiles/trace_chain.py (-DCHAIN_TRACE builds only, never shipped): workgroup
+// 0, waves 0 (group 0) and 4 (group 1), chunks 8..15: s_memtime at the top of the MFMA phase, behind its last product, behind
+// its waits, behind its barrier, at the end of the VALU phase, behind that barrier.
+// which phase of mlp_chain_pair_kernel runs at raised wave priority: 0 none, 1 the MFMA phase, 2 the VALU phase
+#ifndef CHAIN_PRIO
+#define CHAIN_PRIO 1
+#endif
+#ifdef CHAIN_TRACE
+__device__ unsigned long long vkas_chain_trace_buf[2 * 8 * 8];
+#define CHAIN_TR(slot)                                                                                          \
+  if (blockIdx.x == 0 && (tid & 255) == 0 && j >= 8 && j < 16)                                                   \
+  vkas_chain_trace_buf[((tid >> 8) * 8 + (j - 8)) * 8 + (slot)] = __builtin_readcyclecounter()
+#define CHAIN_TR_SB(slot)                  \
+  __builtin_amdgcn_sched_barrier(0);       \
+  CHAIN_TR(slot);                          \
+  __builtin_amdgcn_sched_barrier(0)
+#else
+#define CHAIN_TR(slot)
+#define CHAIN_TR_SB(slot)
+#endif
+
+template <typename T, int KS, int MODE>
+__global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(ChainArgs p) {
+  typedef typename Frag<T>::v8 v8;
+  typedef typename Frag<T>::v4 v4;
+  static_assert(KS % 2 == 0, "the pair splits the 2 KS output column tiles evenly");
+  constexpr int KA = chain_ka(KS);
+  constexpr int IMG = chain_img_elems(KS);       // elements per packed chunk image (GEMM-a tile | GEMM-b tile | bias piece)
+  constexpr int AEL = 32 * KA, BEL = KS * 1024;  // elements of the two tiles
+  constexpr int NIA = AEL * 2 / 1024, NIB = BEL * 2 / 1024;  // 1-KB DMA instructions per tile
+  constexpr int OFF_A = 0, OFF_B = 2 * AEL, OFF_BIAS = OFF_B + 2 * BEL;       // element offsets (T) into the LDS array
+  constexpr int OFF_EX = OFF_BIAS + 4 * 64;                                    // bias: 4 slots x 32 floats (a slot is refilled two chunks ahead, while the chunk before it is still being read)
+  constexpr int OFF_STG = OFF_EX + 2 * 4 * 2 * 64 * 8;                         // exchange: [parity][pair][t][lane] x 8 elements
+  constexpr int LDS_MAIN = OFF_STG + 4 * 2 * 32 * 64;                          // staging: [pair][parity][32 rows][64]
+  constexpr int PE = KS * 16 + 8;                                              // epilogue row pitch: this wave's 16 KS columns
+  constexpr int LDS_EPI = 8 * 32 * PE;
+  constexpr int LDS_ELEMS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+  __shared__ __attribute__((aligned(1024))) T lds[LDS_ELEMS];
+  typedef __attribute__((address_space(3))) T lds_T;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;            // wave group: the two groups run half an iteration apart
+  const int pair = wave >> 1;           // 0..3: 32 rows each
+  const int t = wave & 1;               // half of the pair: hidden units 16 t.., output columns 16 KS t..
+  const int wq = wave & 3;              // index inside the group (DMA shares)
+  const int fr = lane & 15, g = lane >> 4;
+  const int C = p.C;
+  const long row0 = (long)blockIdx.x * 128 + pair * 32;
+  const int nchunks = p.HID / 32;
+  const bool keep_mid = MODE == MODE_BWD || p.mid_out != nullptr;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  // every LDS-DMA request of this kernel goes through vkas_lds_dma16 (vkas_common.h): the waits are the kernel's own
+  const u32x4 rs_w = vkas_make_rsrc(p.img, (unsigned)((long)nchunks * IMG * 2));
+  const unsigned lds0 = vkas_lds_addr(lds);  // LDS byte address of element 0
+  // tile DMA: NI 1-KB instructions starting at byte `src` of the image buffer -> LDS element offset `dst`, dealt over `nw` waves
+  auto issue_tile = [&](unsigned src, int dst, int ni, int w, int nw) {
+    for (int inst = w; inst < ni; inst += nw) {  // wave-uniform trip count
+      const unsigned voff = src + (unsigned)inst * 1024u + (unsigned)lane * 16u;
+      vkas_lds_dma16(rs_w, lds0 + (unsigned)(dst + inst * 512) * 2u, voff);
+    }
+  };
+  auto issue_a = [&](int j, int w, int nw) {  // GEMM-a tile + the chunk's 32 biases (first 128 bytes of the bias piece)
+    const unsigned base = (unsigned)j * (unsigned)(IMG * 2);
+    issue_tile(base, OFF_A + (j & 1) * AEL, NIA, w, nw);
+    if (w == 0 && lane < 8)
+      vkas_lds_dma16(rs_w, lds0 + (unsigned)(OFF_BIAS + (j & 3) * 64) * 2u, base + (unsigned)((AEL + BEL) * 2) + (unsigned)lane * 16u);
+  };
+  auto issue_b = [&](int j, int w, int nw) { issue_tile((unsigned)j * (unsigned)(IMG * 2) + AEL * 2, OFF_B + (j & 1) * BEL, NIB, w, nw); };
+
+  // staging of the 4C-wide tensor, per pair and chunk-pair parity: 32 rows x 128 bytes, 16-byte piece c of row r at position
+  // c ^ ((r >> 1) & 7) (as in the kernel above)
+  auto stg_base_of = [&](int pr, int par2) { return lds + OFF_STG + (pr * 2 + par2) * 2048; };
+  auto stg_base = [&](int par2) { return stg_base_of(pair, par2); };
+  auto stg_off = [&](int r, int e) { return r * 64 + ((((e >> 3) ^ (r >> 1)) & 7) << 3) + (e & 7); };
+  const int f_r = lane >> 3, f_pp = lane & 7;
+  u32x4 rs_h = {0, 0, 0, 0};
+  if constexpr (MODE == MODE_BWD) rs_h = vkas_make_rsrc(p.mid_in, (unsigned)(((p.M - 1) * p.ldmi + p.HID) * 2));
+  // Division of the memory work (round 4): group 1 issues every LDS-DMA request (weight tiles, backward: h) at the start of
+  // its VALU phase and waits for them at the end of its NEXT MFMA phase - a whole phase of slack, and still one barrier before
+  // the first reader; group 0 issues every store of the 4C-wide tensor and never waits for vector memory inside the loop, so a
+  // store's acknowledgement (microseconds) is on nobody's critical path.
+  auto issue_h = [&](int P2) {  // backward: saved pre-activations of chunk pair P2 -> staging, all four pairs (wave wq: pair wq)
+    T* dst = stg_base_of(wq, P2 & 1);
+    const long prow0 = (long)blockIdx.x * 128 + wq * 32;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = it * 8 + f_r;
+      const int c = (f_pp ^ (r >> 1)) & 7;
+      const long m = prow0 + r;
+      const bool ok = m < p.M && P2 * 64 + c * 8 < p.HID;
+      const unsigned voff = ok ? (unsigned)((m * p.ldmi + P2 * 64 + c * 8) * 2) : OOB;
+      vkas_lds_dma16(rs_h, vkas_lds_addr(dst) + (unsigned)(it * 1024), voff);
+    }
+  };
+  auto flush_pair = [&](int P2, int width) {  // staged chunk pair of pair wq -> global (h forward, dh backward)
+    T* G = reinterpret_cast<T*>(p.mid_out);
+    const T* src = stg_base_of(wq, P2 & 1);
+    const long prow0 = (long)blockIdx.x * 128 + wq * 32;
+    v8 v[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const v8*>(src + (it * 8 + f_r) * 64 + f_pp * 8);  // one LDS round trip
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = it * 8 + f_r;
+      const int c = (f_pp ^ (r >> 1)) & 7;
+      const long m = prow0 + r;
+      if (m < p.M && c * 8 < width) *reinterpret_cast<v8*>(G + m * p.ldm + P2 * 64 + c * 8) = v[it];
+    }
+  };
+
+  // prologue: the first two GEMM-a tiles, the first GEMM-b tile, (backward) the first two chunk pairs of h
+  issue_a(0, wave, 8);
+  issue_b(0, wave, 8);
+  if (nchunks > 1) issue_a(1, wave, 8);
+  if constexpr (MODE == MODE_BWD) {
+    if (grp == 1) {
+      issue_h(0);
+      if (nchunks > 2) issue_h(1);
+    }
+  }
+  // this wave's 16 input rows (row group t of the pair) -> B fragments (row fr, k = ks*32 + g*8 .. +7), resident for the
+  // whole kernel
+  v8 xf[KS];
+  {
+    const T* A = reinterpret_cast<const T*>(p.a);
+    const long m = row0 + t * 16 + fr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = ks * 32 + g * 8;
+      v8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (m < p.M && k < C) v = *reinterpret_cast<const v8*>(A + m * p.lda + k);
+      xf[ks] = v;
+    }
+  }
+  f32x4 acc[2][KS];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int n = 0; n < KS; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one interval behind group 0
+
+  f32x4 d[2];  // GEMM-a result of this wave's row group: hidden units 4g .. 4g+3 (d[0]) and 16 + 4g .. (d[1]) of the chunk
+  v8 own;      // ... after the elementwise middle: exactly one K = 32 B fragment of GEMM-b (k permutation of the weight image)
+  v4 hq[2];    // backward: the saved pre-activations of this lane's 8 hidden units, read from the staging buffer in the MFMA phase
+  T* exch = lds + OFF_EX;
+  // One MFMA phase = GEMM-b of chunk jb (12 weight fragments, two products each; skipped for jb < 0) and GEMM-a of chunk ja
+  // (2 KS fragments, one product each; skipped for ja < 0), fragments in batches of FB: the reads of a batch are issued before
+  // the products of the batch in front of it, so only the first batch's LDS latency is exposed (measured: a batch whose reads
+  // stand directly in front of its own products costs 200 - 300 cycles of LDS latency per batch with every wave of the group
+  // reading at once).  Forward: the chunk's biases are read with the first batch and become GEMM-a's initial accumulators.
+  constexpr int FB = 6;
+  const int b_lane = (fr >> 1) * 64 + ((((fr & 1) * 4 + g) ^ ((fr >> 1) & 7)) << 3);
+  const int a_lane[2] = {fr * 64 + ((g ^ (fr & 7)) << 3), fr * 64 + (((4 + g) ^ (fr & 7)) << 3)};
+  constexpr int NB_B = (KS + FB - 1) / FB, NB_A = (2 * KS) / FB;  // batches of GEMM-b / GEMM-a
+  static_assert((2 * KS) % FB == 0, "GEMM-a fragments in whole batches");
+  auto mfma_phase = [&](auto has_b_c, auto has_a_c, int jb, int ja) __attribute__((always_inline)) {
+    constexpr bool HAS_B = decltype(has_b_c)::value, HAS_A = decltype(has_a_c)::value;  // compile-time: the buffer slots are too
+    v8 fr_[2][FB];
+    v8 gf[2];
+    const T* Wb = lds + OFF_B + (jb & 1) * BEL;
+    const T* Wa = lds + OFF_A + (ja & 1) * AEL;
+    auto read_b = [&](int bb, int slot) {
+#pragma unroll
+      for (int u = 0; u < FB; ++u) {
+        const int n = bb * FB + u;
+        if (n >= KS) break;
+        // row (t KS + n) 16 + fr of the [C / 2][64] view: R = row >> 1 = (t KS + n) 8 + (fr >> 1), R & 7 = fr >> 1, so the
+        // swizzled position is a per-lane constant and the fragment address is lane base + 512 n elements (an immediate)
+        if ((ABL & 32) && n > 0) fr_[slot][u] = xf[0];  // timing only: one fragment read per phase
+        else fr_[slot][u] = *reinterpret_cast<const v8*>(Wb + (t * KS + n) * 512 + b_lane);
+      }
+    };
+    auto read_a = [&](int ab, int slot) {  // fragment f of GEMM-a: k step f >> 1, hidden half f & 1
+#pragma unroll
+      for (int u = 0; u < FB; ++u) {
+        const int f = ab * FB + u;
+        const int ks = f >> 1, tt = f & 1;
+        // hidden row h = 16 tt + fr of sub-tile ks >> 1: (h & 7) = fr & 7, so two per-lane constants (k-step parity) + immediates
+        if ((ABL & 32) && f > 0) fr_[slot][u] = xf[0];
+        else fr_[slot][u] = *reinterpret_cast<const v8*>(Wa + (ks >> 1) * 2048 + tt * 1024 + a_lane[ks & 1]);
+      }
+    };
+    auto mul_b = [&](int bb, int slot) {
+#pragma unroll
+      for (int u = 0; u < FB; ++u) {
+        const int n = bb * FB + u;
+        if (n >= KS) break;
+        acc[0][n] = mfma16(fr_[slot][u], gf[0], acc[0][n]);
+        acc[1][n] = mfma16(fr_[slot][u], gf[1], acc[1][n]);
+      }
+    };
+    auto mul_a = [&](int ab, int slot) {
+#pragma unroll
+      for (int u = 0; u < FB; ++u) {
+        const int f = ab * FB + u;
+        d[f & 1] = mfma16(fr_[slot][u], xf[f >> 1], d[f & 1]);
+      }
+    };
+    if constexpr (HAS_B) {
+      const v8 other = *reinterpret_cast<const v8*>(exch + (((jb & 1) * 4 + pair) * 2 + (1 - t)) * 512 + lane * 8);
+      read_b(0, 0);
+      gf[0] = t == 0 ? own : other;
+      gf[1] = t == 0 ? other : own;
+    }
+    if constexpr (HAS_A) {
+      if constexpr (MODE == MODE_FWD) {
+        const float* Ba = reinterpret_cast<const float*>(lds + OFF_BIAS + (ja & 3) * 64);
+        d[0] = *reinterpret_cast<const f32x4*>(Ba + g * 4);
+        d[1] = *reinterpret_cast<const f32x4*>(Ba + 16 + g * 4);
+      } else {
+        d[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        d[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int e0 = (ja & 1) * 32 + g * 4;
+        const T* stg = stg_base((ja >> 1) & 1);
+        hq[0] = *reinterpret_cast<const v4*>(stg + stg_off(t * 16 + fr, e0));
+        hq[1] = *reinterpret_cast<const v4*>(stg + stg_off(t * 16 + fr, e0 + 16));
+      }
+      if constexpr (!HAS_B) read_a(0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int S0 = HAS_B ? NB_B : 0;  // batches in front of GEMM-a's first one: its buffer slot is S0 & 1
+    if constexpr (HAS_B) {
+#pragma unroll
+      for (int bb = 0; bb < NB_B; ++bb) {
+        // the next batch's reads (GEMM-b's next batch, or GEMM-a's first one) in front of this batch's products
+        if (bb + 1 < NB_B) read_b(bb + 1, (bb + 1) & 1);
+        else if constexpr (HAS_A) read_a(0, S0 & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mul_b(bb, bb & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (HAS_A) {
+#pragma unroll
+      for (int ab = 0; ab < NB_A; ++ab) {
+        if (ab + 1 < NB_A) read_a(ab + 1, (S0 + ab + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mul_a(ab, (S0 + ab) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  // one chunk = an MFMA phase and a VALU phase, each closed by a barrier; the first chunk (no GEMM-b yet) is peeled off the
+  // loop so that the loop body has one shape (with both shapes behind a branch inside the loop the register allocator kept
+  // two copies of the accumulators: 135 spilled registers)
+  auto chunk = [&](auto no_b_c, int j) __attribute__((always_inline)) {
+    constexpr bool NO_B = decltype(no_b_c)::value;
+    std::integral_constant<bool, !NO_B> first_c;  // "has GEMM-b"
+    CHAIN_TR(0);
+    // ---------------- MFMA phase: GEMM-b of chunk j - 1, GEMM-a of chunk j
+    if constexpr (CHAIN_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+    mfma_phase(first_c, std::true_type{}, j - 1, j);
+    if constexpr (CHAIN_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    CHAIN_TR(1);
+    if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requests of its previous VALU phase have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CHAIN_TR(2);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    CHAIN_TR(3);
+    if constexpr (CHAIN_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+    // ---------------- VALU phase of chunk j
+    // Group 1 (this is interval 2 j + 2): GEMM-a tile of chunk j + 2 (its slot was last read by this group's MFMA phase that
+    // just ended; first read by group 0 in interval 2 j + 4) and GEMM-b tile of chunk j + 1 (likewise); waited for at the end
+    // of this group's next MFMA phase (interval 2 j + 3).
+    if (grp == 1) {
+      if (!(ABL & 16)) {
+        if (j + 2 < nchunks) issue_a(j + 2, wq, 4);
+        if (j + 1 < nchunks) issue_b(j + 1, wq, 4);
+      }
+      if constexpr (MODE == MODE_BWD) {
+        // h of chunk pair Q + 2 (Q = j / 2 - 1) into the buffer of pair Q, which group 0 flushed in the interval that just
+        // ended; landed (this group's wait at the end of its next MFMA phase) two intervals before its first reader
+        if ((j & 1) == 0 && j >= 2 && (j >> 1) + 1 < (nchunks + 1) / 2 && !(ABL & 1)) issue_h((j >> 1) + 1);
+      }
+    } else if (keep_mid && !(ABL & 1) && (j & 1) == 0 && j >= 2) {
+      // Group 0 (interval 2 j + 1): chunk pair (j >> 1) - 1 of all four pairs is complete (group 1 wrote its last part in
+      // interval 2 j - 2 ... wait for nothing: the stores stay in flight
+      flush_pair((j >> 1) - 1, 64);
+    }
+    {
+      const int e0 = (j & 1) * 32 + g * 4;   // this lane's hidden units e0 .. e0+3 and e0+16 .. e0+19 of the chunk pair's 64
+      const int r = t * 16 + fr;             // its row inside the pair's 32
+      T* stg = stg_base((j >> 1) & 1);
+      v4 h0, h1;
+      if constexpr (MODE == MODE_FWD) {
+        h0[0] = (T)d[0][0]; h0[1] = (T)d[0][1]; h0[2] = (T)d[0][2]; h0[3] = (T)d[0][3];  // (the accumulators started from the bias)
+        h1[0] = (T)d[1][0]; h1[1] = (T)d[1][1]; h1[2] = (T)d[1][2]; h1[3] = (T)d[1][3];
+        if (keep_mid) {
+          *reinterpret_cast<v4*>(stg + stg_off(r, e0)) = h0;
+          *reinterpret_cast<v4*>(stg + stg_off(r, e0 + 16)) = h1;
+        }
+        CHAIN_TR_SB(6);
+        // GELU of the stored (rounded) pre-activation: what backward will differentiate
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          own[q] = (ABL & 4) ? h0[q] : (T)gelu_t<T>((float)h0[q]);
+          own[4 + q] = (ABL & 4) ? h1[q] : (T)gelu_t<T>((float)h1[q]);
+        }
+        CHAIN_TR_SB(7);
+      } else {
+        h0 = hq[0];
+        h1 = hq[1];
+        v4 o0, o1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          o0[q] = (T)(d[0][q] * ((ABL & 4) ? (float)h0[q] : dgelu_t<T>((float)h0[q])));
+          o1[q] = (T)(d[1][q] * ((ABL & 4) ? (float)h1[q] : dgelu_t<T>((float)h1[q])));
+          own[q] = o0[q];
+          own[4 + q] = o1[q];
+        }
+        *reinterpret_cast<v4*>(stg + stg_off(r, e0)) = o0;  // in place: dh over h
+        *reinterpret_cast<v4*>(stg + stg_off(r, e0 + 16)) = o1;
+      }
+      *reinterpret_cast<v8*>(exch + (((j & 1) * 4 + pair) * 2 + t) * 512 + lane * 8) = own;
+    }
+    if constexpr (CHAIN_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CHAIN_TR(4);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    CHAIN_TR(5);
+  };
+  chunk(std::true_type{}, 0);
+  for (int j = 1; j < nchunks; ++j) chunk(std::false_type{}, j);
+  // last GEMM-b; then group 0 (one barrier ahead: group 1's last VALU phase has ended by then) stores the last chunk pair
+  mfma_phase(std::true_type{}, std::false_type{}, nchunks - 1, -1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (grp == 0) {
+    __builtin_amdgcn_s_barrier();  // every wave passes the same number of barriers
+    asm volatile("" ::: "memory");
+    if (keep_mid && !(ABL & 1)) flush_pair((nchunks - 1) >> 1, (nchunks & 1) ? 32 : 64);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();    // nobody reads the weight rings or the staging buffers any more
+  asm volatile("" ::: "memory");
+
+  // ---- epilogue: this wave's 32 rows x 16 KS columns through a per-wave LDS tile, then whole 16-byte row pieces
+  T* ep = lds + wave * (32 * PE);
+  const int col0 = t * KS * 16;
+#pragma unroll
+  for (int n = 0; n < KS; ++n) {
+    const int col = n * 16 + g * 4;
+    float4 b2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (MODE == MODE_FWD) {
+      if (col0 + col < C) b2 = *reinterpret_cast<const float4*>(p.bias_b + col0 + col);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      v4 zq;
+      zq[0] = (T)(acc[i][n][0] + b2.x);
+      zq[1] = (T)(acc[i][n][1] + b2.y);
+      zq[2] = (T)(acc[i][n][2] + b2.z);
+      zq[3] = (T)(acc[i][n][3] + b2.w);
+      *reinterpret_cast<v4*>(ep + (i * 16 + fr) * PE + col) = zq;
+    }
+  }
+  constexpr int PCS = KS * 2;        // 16-byte pieces of this wave's part of a row
+  constexpr int RPI = 64 / PCS;      // rows per instruction
+  const int piece = lane % PCS, rsub = lane / PCS;
+  const int gcol = col0 + piece * 8;
+  if (rsub < RPI && gcol < C) {
+    float cs[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) cs[q] = 0.f;
+    if constexpr (MODE == MODE_FWD) load8(p.colscale + gcol, cs);
+#pragma unroll 4
+    for (int r = rsub; r < 32; r += RPI) {
+      const long m = row0 + r;
+      if (m >= p.M) break;
+      const v8 zq = *reinterpret_cast<const v8*>(ep + r * PE + piece * 8);
+      if constexpr (MODE == MODE_FWD) {
+        // z is stored in the activation type and the residual uses the rounded value (as the two-kernel path does)
+        if (p.z) *reinterpret_cast<v8*>(reinterpret_cast<T*>(p.z) + m * p.ldz + gcol) = zq;
+        const float rs = p.rowscale ? p.rowscale[(int)(m / p.rows_per_image)] : 1.0f;
+        float xr[8];
+        load8(reinterpret_cast<const T*>(p.res) + m * p.ldres + gcol, xr);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xr[q] += rs * cs[q] * (float)zq[q];
+        store8(reinterpret_cast<T*>(p.out) + m * p.ldo + gcol, xr);
+      } else {
+        *reinterpret_cast<v8*>(reinterpret_cast<T*>(p.out) + m * p.ldo + gcol) = zq;
+      }
+    }
+  }
+}
+
 // KS (32-wide K steps covering C) and rows per wave for a channel count, 0 when the chain kernels do not cover it
 static int chain_ks(int C) {
   if (C <= 0 || C % 8 != 0 || C > 512) return 0;
   const int ks = (C + 31) / 32;
   return ks <= 4 ? ks : (ks <= 6 ? 6 : (ks <= 8 ? 8 : (ks <= 12 ? 12 : 16)));
+}
+
+static bool chain_pair_enabled() {
+  static const bool on = [] {
+    const char* v = getenv("VKAS_CHAIN_PAIR");
+    return !(v && v[0] == '0');
+  }();
+  return on;
 }
 
 template <typename T, int MODE>
@@ -467,7 +914,15 @@ static int launch_chain(const ChainArgs& a, hipStream_t st) {
     case 8: VKAS_CHAIN(8, 2, 1) break;
     // 384 / 512 channels (stage 2 of Tiny / Base): one workgroup of four 512-register waves per CU; the weight images
     // (49 / 65 KB per chunk) stream from L2, 128 rows per workgroup keep that stream under the L2 -> LDS rate
-    case 12: VKAS_CHAIN(12, 2, 1) break;
+    case 12:
+      // 256 < C <= 384: the pair-split kernel (two 256-register waves per SIMD); VKAS_CHAIN_PAIR=0 keeps the one-wave form
+      if (a.C % 16 == 0 && chain_pair_enabled()) {
+        const unsigned grid = (unsigned)vkas_cdiv(a.M, 128);
+        mlp_chain_pair_kernel<T, 12, MODE><<<grid, 512, 0, st>>>(a);
+      } else {
+        VKAS_CHAIN(12, 2, 1)
+      }
+      break;
     case 16: VKAS_CHAIN(16, 2, 1) break;
     default:
       vkas_set_error("vkas_mlp_chain: C=%d is not covered (multiple of 8, <= 512)", a.C);
@@ -554,3 +1009,9 @@ extern "C" int vkas_mlp_chain_bwd(const void* dz, long lddz, const void* img_t, 
   VKAS_LAUNCH_CHECK("mlp_chain_bwd");
   return VKAS_OK;
 }
+
+#ifdef CHAIN_TRACE
+extern "C" int vkas_chain_trace_read(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(vkas_chain_trace_buf), bytes < sizeof(vkas_chain_trace_buf) ? bytes : sizeof(vkas_chain_trace_buf));
+}
+#endif

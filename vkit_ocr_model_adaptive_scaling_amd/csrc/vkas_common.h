@@ -233,3 +233,24 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 template <> __device__ __forceinline__ float dgelu_t<f16_t>(float x) { return dgelu_t<bf16_t>(x); }
+
+// ---- LDS-DMA with the waits in the kernel's hands ------------------------------------------------------------------
+// `buffer_load_dwordx4 ... lds` (1 KB per wave instruction: lane l's 16 bytes land at lds_addr + 16 l) written as inline
+// assembly.  The compiler's own builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) makes SIInsertWaitcnts treat every later LDS
+// access whose memory operand survived to that pass as possibly aliasing the DMA's destination: it then inserts
+// `s_waitcnt vmcnt(0)` in front of it - found in round 4 in front of the fp32 bias read of mlp_chain_kernel, i.e. the "prefetch"
+// of the next weight chunk was waited for at the top of every chunk.  A DMA the pass cannot see is ordered by the kernel's own
+// counted `s_waitcnt vmcnt(N)` + barrier (which these kernels carry anyway); instructions the pass does know can only be
+// over-waited for by it, never under-waited (vmcnt retires in order).
+// rs: buffer descriptor words (base, base_hi | stride, num_records bytes, flags); lds_addr: wave-uniform LDS byte address.
+__device__ __forceinline__ u32x4 vkas_make_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  u32x4 r = {(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
+  return r;
+}
+__device__ __forceinline__ void vkas_lds_dma16(u32x4 rs, unsigned lds_addr, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+}
+template <typename T> __device__ __forceinline__ unsigned vkas_lds_addr(const T* p) {
+  return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) T*)p;
+}

@@ -269,15 +269,20 @@ def _cached_pack_pair(a: torch.Tensor, b: torch.Tensor, key, build):
 _NO_CHAIN = os.environ.get('VKAS_NO_MLP_CHAIN') is not None  # A/B switch: force the two-GEMM layer path
 
 
-# The kernels exist up to 512 channels, but beyond 256 a workgroup streams 49 - 65 KB of weights per 32 hidden units
-# through LDS with one wave per SIMD and measured no faster than the two-GEMM path (stage 2 of ConvNeXt-T: 0.31 ms per
-# layer and direction either way), so the layer op uses them up to 256 channels; tests raise the limit to cover the rest.
-_CHAIN_MAX_C = int(os.environ.get('VKAS_MLP_CHAIN_MAX_C', '256'))
+# The kernels exist up to 512 channels.  Up to 256 channels and - round 4, the pair-split kernel with two 256-register waves per
+# SIMD (csrc/mlp_chain.hip::mlp_chain_pair_kernel) - for 256 < C <= 384 with C % 16 == 0 (stage 2 of ConvNeXt-T / -S) the
+# fused kernels beat the two-GEMM path (stage 2 of config #3: 0.23 + 0.21 ms per layer against 0.29 + 0.29); at 512 channels
+# (ConvNeXt-Base) the one-wave-per-SIMD instantiation measured no faster than two GEMMs, so that width stays on the GEMMs.
+_CHAIN_MAX_C = int(os.environ.get('VKAS_MLP_CHAIN_MAX_C', '384'))
+
+
+def _chain_width_ok(C: int) -> bool:
+    return C <= min(_CHAIN_MAX_C, 256) or (256 < C <= min(_CHAIN_MAX_C, 384) and C % 16 == 0) or (384 < C <= _CHAIN_MAX_C)
 
 
 def mlp_chain_eligible(x: torch.Tensor, C: int) -> bool:
     """The fused ConvNeXt MLP kernels (csrc/mlp_chain.hip) cover 16-bit activations with C % 8 == 0, C <= 512."""
-    return (not _NO_CHAIN and x.dtype in _MFMA_DTYPES and x.shape[3] == C and C <= _CHAIN_MAX_C
+    return (not _NO_CHAIN and x.dtype in _MFMA_DTYPES and x.shape[3] == C and _chain_width_ok(C)
             and lib.vkas_mlp_chain_image_elems(C) > 0)
 
 
