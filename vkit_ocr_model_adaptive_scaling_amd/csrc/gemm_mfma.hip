@@ -1176,9 +1176,13 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const elem_t* _
   const int hpos = hc & 15;
   const int hl = (((hpos >> 1) ^ hrow) << 1) | (hpos & 1);   // (64 + hrow) & 7 = hrow
   const bool hx_ok = cb * WG_C + hl * 8 < Cp;
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, (short)0, (int)x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)dy, (short)0, (int)dy_bytes, 0x00020000);
-  typedef __attribute__((address_space(3))) void* lds_ptr;
+  // LDS-DMA through vkas_lds_dma16 (inline assembly, vkas_common.h), not the compiler's builtin (round 4): with the builtin,
+  // SIInsertWaitcnts put an `s_waitcnt vmcnt(0)` in front of the first transposing read of EVERY chunk (the ds_read_tr
+  // builtins carry memory operands it takes for aliases of the DMA destinations) - the two chunks this kernel keeps in flight
+  // behind the one being read (counted vmcnt(10) / vmcnt(8) below) were drained at the top of every iteration.
+  const u32x4 rs_x = vkas_make_rsrc(x, x_bytes);
+  const u32x4 rs_d = vkas_make_rsrc(dy, dy_bytes);
+  const unsigned lds_dma0 = vkas_lds_addr(lds);
   // issue cursor: chunk -> (image, row, first pixel); 64 | W keeps a chunk inside one image row
   long ic = c_beg;
   int i_b, i_y, i_x;
@@ -1191,8 +1195,8 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const elem_t* _
     i_x = rem - i_y * W;
   }
   auto issue_chunk = [&](int buf) {  // 5 instructions per wave
-    elem_t* Ds = lds + buf * WG_BUF;
-    elem_t* Xs = Ds + WG_DY;
+    const unsigned Ds = lds_dma0 + (unsigned)(buf * WG_BUF) * 2u;  // LDS byte addresses of the chunk buffer's dy / x parts
+    const unsigned Xs = Ds + (unsigned)WG_DY * 2u;
     const unsigned d_base = (unsigned)(ic * WG_ROWS * lddy) * 2u;
     const int iy = i_y + ky - 1;
     const bool row_ok = (unsigned)iy < (unsigned)H;
@@ -1203,19 +1207,19 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_slab_kernel(const elem_t* _
     for (int q = 0; q < 2; ++q) {
       if (q == 1 && d_count == 1) break;  // wave-uniform
       const unsigned vd = d_ok[q] ? d_base + d_lane[q] : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lds_ptr)(Ds + (q * 8 + wave) * 512), 16, vd, 0, 0, 0);
+      vkas_lds_dma16(rs_d, Ds + (unsigned)((q * 8 + wave) * 1024), vd);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const unsigned vx = (row_ok && x_ok) ? x_base + xl + (unsigned)(q * 32 * g.ldx * 2) : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(Xs + (q * 8 + wave) * 512), 16, vx, 0, 0, 0);
+      vkas_lds_dma16(rs_x, Xs + (unsigned)((q * 8 + wave) * 1024), vx);
     }
     {
       const int hpix = hrow == 0 ? i_x - 1 : i_x + WG_ROWS;
       const bool ok = row_ok && hx_ok && (unsigned)hpix < (unsigned)W;
       const unsigned vh = ok ? (unsigned)(((i_b * H + iy) * W + hpix) * g.ldx + cb * WG_C + hl * 8) * 2u : OOB;
       if (lane < 4)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(Xs + 64 * WG_C + wave * 32), 16, vh, 0, 0, 0);
+        vkas_lds_dma16(rs_x, Xs + (unsigned)((64 * WG_C + wave * 32) * 2), vh);
     }
     ++ic;
     i_x += WG_ROWS;

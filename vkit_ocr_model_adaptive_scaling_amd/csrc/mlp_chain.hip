@@ -888,12 +888,13 @@ static int chain_ks(int C) {
   return ks <= 4 ? ks : (ks <= 6 ? 6 : (ks <= 8 ? 8 : (ks <= 12 ? 12 : 16)));
 }
 
-static bool chain_pair_enabled() {
-  static const bool on = [] {
+// VKAS_CHAIN_PAIR=0: the one-wave-per-SIMD kernel at 256 < C <= 384 instead of the pair-split kernel (A/B switch)
+static int chain_pair_mode() {
+  static const int mode = [] {
     const char* v = getenv("VKAS_CHAIN_PAIR");
-    return !(v && v[0] == '0');
+    return (v && v[0] == '0') ? 0 : 1;
   }();
-  return on;
+  return mode;
 }
 
 template <typename T, int MODE>
@@ -916,7 +917,7 @@ static int launch_chain(const ChainArgs& a, hipStream_t st) {
     // (49 / 65 KB per chunk) stream from L2, 128 rows per workgroup keep that stream under the L2 -> LDS rate
     case 12:
       // 256 < C <= 384: the pair-split kernel (two 256-register waves per SIMD); VKAS_CHAIN_PAIR=0 keeps the one-wave form
-      if (a.C % 16 == 0 && chain_pair_enabled()) {
+      if (a.C % 16 == 0 && chain_pair_mode() != 0) {
         const unsigned grid = (unsigned)vkas_cdiv(a.M, 128);
         mlp_chain_pair_kernel<T, 12, MODE><<<grid, 512, 0, st>>>(a);
       } else {
