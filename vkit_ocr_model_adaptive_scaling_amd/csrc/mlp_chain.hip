@@ -133,6 +133,13 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
   typedef typename Frag<T>::v8 v8;
   typedef typename Frag<T>::v4 v4;
   constexpr int NT2 = 2 * KS;                // 16-wide output column tiles of GEMM-b
+  // fragment reads of a chunk's products hoisted in front of them and the 4C-wide stores batched (round 4): -5 ... -23 % from
+  // 128 channels on; at <= 96 channels (TM = 4: 256 registers) the extra live fragments spill and it is 3 % slower
+#ifdef CHAIN_OLD_SCHED
+  constexpr bool HOIST = false;
+#else
+  constexpr bool HOIST = KS >= 4;
+#endif
   constexpr int KA = chain_ka(KS);
   constexpr int IMG = chain_img_elems(KS);   // elements per chunk image
   constexpr int NI = IMG * 2 / 1024;         // 1-KB DMA instructions per chunk image
@@ -214,6 +221,19 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
   // staged pair -> global (h forward, dh backward): 8 rows x 128 B per instruction, whole cache lines
   auto flush_pair = [&](int P, int width) {
     T* G = reinterpret_cast<T*>(p.mid_out);
+    if constexpr (HOIST) {
+    // all pieces read first (one LDS round trip instead of NF: each read stood in front of its own store)
+    v8 v[NF];
+#pragma unroll
+    for (int it = 0; it < NF; ++it) v[it] = *reinterpret_cast<const v8*>(stg + (it * 8 + f_r) * 64 + f_pp * 8);
+#pragma unroll
+    for (int it = 0; it < NF; ++it) {
+      const int r = it * 8 + f_r;
+      const int c = (f_pp ^ (r >> 1)) & 7;
+      const long m = row0 + r;
+      if (m < p.M && c * 8 < width && !(ABL & 1)) *reinterpret_cast<v8*>(G + m * p.ldm + P * 64 + c * 8) = v[it];
+    }
+    } else {
 #pragma unroll 2
     for (int it = 0; it < NF; ++it) {
       const int r = it * 8 + f_r;
@@ -221,6 +241,7 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
       const long m = row0 + r;
       const v8 v = *reinterpret_cast<const v8*>(stg + r * 64 + f_pp * 8);
       if (m < p.M && c * 8 < width && !(ABL & 1)) *reinterpret_cast<v8*>(G + m * p.ldm + P * 64 + c * 8) = v;
+    }
     }
   };
 
@@ -263,6 +284,37 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
       d[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
       d[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    if constexpr (HOIST) {
+    {
+      // every weight fragment of the chunk's GEMM-a is requested before the first product (the scheduler otherwise pairs each
+      // read with its use: one LDS latency per k step in front of 2 TM products)
+      constexpr int KB = KS < 8 ? KS : KS / 2;   // k steps per batch (KS >= 8: two batches keep the fragments within 64 registers)
+#pragma unroll
+      for (int k0 = 0; k0 < KS; k0 += KB) {
+        v8 wa[KB][2];
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+          const int ks = k0 + kk;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int h = t * 16 + fr;
+            const int c = (ks & 1) * 4 + g;
+            wa[kk][t] = *reinterpret_cast<const v8*>(Wa + (ks >> 1) * 2048 + h * 64 + ((c ^ (h & 7)) << 3));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            d[i][0] = mfma16(wa[kk][0], xf[i][k0 + kk], d[i][0]);
+            d[i][1] = mfma16(wa[kk][1], xf[i][k0 + kk], d[i][1]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       v8 wa[2];
@@ -277,6 +329,7 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
         d[i][0] = mfma16(wa[0], xf[i][ks], d[i][0]);
         d[i][1] = mfma16(wa[1], xf[i][ks], d[i][1]);
       }
+    }
     }
     // ---- elementwise middle: the GEMM-b operand of this chunk, built in registers; the 4C-wide values go through the
     //      pair staging buffer (this lane: hidden units e0 .. e0+3 and e0+16 .. e0+19 of the pair's 64)
@@ -345,6 +398,32 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
       }
     }
     // ---- GEMM-b: acc[i][n] += Wb[n rows][32 k slots] . gf[i]
+    if constexpr (HOIST) {
+    {
+      constexpr int NBB = NT2 <= 12 ? NT2 : 8;  // fragments per batch
+#pragma unroll
+      for (int n0 = 0; n0 < NT2; n0 += NBB) {
+        v8 wb[NBB];
+#pragma unroll
+        for (int u = 0; u < NBB; ++u) {
+          const int n = n0 + u;
+          if (n >= NT2) break;
+          const int row = n * 16 + fr;
+          const int R = row >> 1, c = (row & 1) * 4 + g;
+          wb[u] = *reinterpret_cast<const v8*>(Wb + R * 64 + ((c ^ (R & 7)) << 3));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NBB; ++u) {
+          const int n = n0 + u;
+          if (n >= NT2) break;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) acc[i][n] = mfma16(wb[u], gf[i], acc[i][n]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    } else {
 #pragma unroll
     for (int n = 0; n < NT2; ++n) {
       const int row = n * 16 + fr;
@@ -352,6 +431,7 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
       const v8 wb = *reinterpret_cast<const v8*>(Wb + R * 64 + ((c ^ (R & 7)) << 3));
 #pragma unroll
       for (int i = 0; i < TM; ++i) acc[i][n] = mfma16(wb, gf[i], acc[i][n]);
+    }
     }
     // The next chunk's image (issued at the top of this iteration) must have landed.  What this chunk issued after it
     // - the flush stores and, backward, the next pair's h DMA - is younger and stays in flight: a full drain (which
