@@ -589,34 +589,41 @@ __device__ unsigned long long vkas_chain_trace_buf[2 * 8 * 8];
 #define CHAIN_TR_SB(slot)
 #endif
 
-template <typename T, int KS, int MODE>
+template <typename T, int KS, int TM, int MODE>
 __global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(ChainArgs p) {
+  // TM = 16-row groups per wave in GEMM-a (a pair owns 2 TM groups = 32 TM rows, a workgroup 128 TM rows).  Shipped: KS = 12,
+  // TM = 1 (256 < C <= 384).  KS = 6, TM = 2 (128 < C <= 192: the same 48 + 96 resident registers, every GEMM-a fragment
+  // feeding two products and every GEMM-b fragment four) was built, is correct and measured SLOWER than mlp_chain_kernel<6, 2>
+  // at stage 1 of config #3 (0.35 / 0.46 ms forward / backward against 0.33 / 0.32): profiles/experiments/README.md.
   typedef typename Frag<T>::v8 v8;
   typedef typename Frag<T>::v4 v4;
   static_assert(KS % 2 == 0, "the pair splits the 2 KS output column tiles evenly");
+  constexpr int RP = 32 * TM;                    // rows of a pair
+  constexpr int RG = 2 * TM;                     // 16-row groups of a pair
   constexpr int KA = chain_ka(KS);
   constexpr int IMG = chain_img_elems(KS);       // elements per packed chunk image (GEMM-a tile | GEMM-b tile | bias piece)
   constexpr int AEL = 32 * KA, BEL = KS * 1024;  // elements of the two tiles
   constexpr int NIA = AEL * 2 / 1024, NIB = BEL * 2 / 1024;  // 1-KB DMA instructions per tile
   constexpr int OFF_A = 0, OFF_B = 2 * AEL, OFF_BIAS = OFF_B + 2 * BEL;       // element offsets (T) into the LDS array
   constexpr int OFF_EX = OFF_BIAS + 4 * 64;                                    // bias: 4 slots x 32 floats (a slot is refilled two chunks ahead, while the chunk before it is still being read)
-  constexpr int OFF_STG = OFF_EX + 2 * 4 * 2 * 64 * 8;                         // exchange: [parity][pair][t][lane] x 8 elements
-  constexpr int LDS_MAIN = OFF_STG + 4 * 2 * 32 * 64;                          // staging: [pair][parity][32 rows][64]
+  constexpr int OFF_STG = OFF_EX + 2 * 4 * 2 * TM * 64 * 8;                    // exchange: [parity][pair][t][row group][lane] x 8 elements
+  constexpr int LDS_MAIN = OFF_STG + 4 * 2 * RP * 64;                          // staging: [pair][parity][RP rows][64]
   constexpr int PE = KS * 16 + 8;                                              // epilogue row pitch: this wave's 16 KS columns
-  constexpr int LDS_EPI = 8 * 32 * PE;
+  constexpr int LDS_EPI = 8 * RP * PE;
   constexpr int LDS_ELEMS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+  static_assert(LDS_ELEMS * 2 <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(1024))) T lds[LDS_ELEMS];
   typedef __attribute__((address_space(3))) T lds_T;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;            // wave group: the two groups run half an iteration apart
-  const int pair = wave >> 1;           // 0..3: 32 rows each
-  const int t = wave & 1;               // half of the pair: hidden units 16 t.., output columns 16 KS t..
-  const int wq = wave & 3;              // index inside the group (DMA shares)
+  const int pair = wave >> 1;           // 0..3: RP rows each
+  const int t = wave & 1;               // half of the pair: row groups t TM .. in GEMM-a, output columns 16 KS t .. in GEMM-b
+  const int wq = wave & 3;              // index inside the group (DMA / store shares: pair wq)
   const int fr = lane & 15, g = lane >> 4;
   const int C = p.C;
-  const long row0 = (long)blockIdx.x * 128 + pair * 32;
+  const long row0 = (long)blockIdx.x * (4 * RP) + pair * RP;
   const int nchunks = p.HID / 32;
   const bool keep_mid = MODE == MODE_BWD || p.mid_out != nullptr;
   constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -639,23 +646,24 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(ChainArgs p) {
   };
   auto issue_b = [&](int j, int w, int nw) { issue_tile((unsigned)j * (unsigned)(IMG * 2) + AEL * 2, OFF_B + (j & 1) * BEL, NIB, w, nw); };
 
-  // staging of the 4C-wide tensor, per pair and chunk-pair parity: 32 rows x 128 bytes, 16-byte piece c of row r at position
+  // staging of the 4C-wide tensor, per pair and chunk-pair parity: RP rows x 128 bytes, 16-byte piece c of row r at position
   // c ^ ((r >> 1) & 7) (as in the kernel above)
-  auto stg_base_of = [&](int pr, int par2) { return lds + OFF_STG + (pr * 2 + par2) * 2048; };
+  auto stg_base_of = [&](int pr, int par2) { return lds + OFF_STG + (pr * 2 + par2) * (RP * 64); };
   auto stg_base = [&](int par2) { return stg_base_of(pair, par2); };
   auto stg_off = [&](int r, int e) { return r * 64 + ((((e >> 3) ^ (r >> 1)) & 7) << 3) + (e & 7); };
   const int f_r = lane >> 3, f_pp = lane & 7;
   u32x4 rs_h = {0, 0, 0, 0};
   if constexpr (MODE == MODE_BWD) rs_h = vkas_make_rsrc(p.mid_in, (unsigned)(((p.M - 1) * p.ldmi + p.HID) * 2));
-  // Division of the memory work (round 4): group 1 issues every LDS-DMA request (weight tiles, backward: h) at the start of
-  // its VALU phase and waits for them at the end of its NEXT MFMA phase - a whole phase of slack, and still one barrier before
-  // the first reader; group 0 issues every store of the 4C-wide tensor and never waits for vector memory inside the loop, so a
-  // store's acknowledgement (microseconds) is on nobody's critical path.
+  // Division of the memory work: group 1 issues every LDS-DMA request (weight tiles, backward: h) at the start of its VALU
+  // phase and waits for them at the end of its NEXT MFMA phase - a whole phase of slack, and still one barrier before the first
+  // reader; group 0 issues every store of the 4C-wide tensor and never waits for vector memory inside the loop, so a store's
+  // acknowledgement (microseconds) is on nobody's critical path.
+  constexpr int NFP = RP / 8;  // 1-KB pieces (8 rows x 128 B) of a pair's staging buffer
   auto issue_h = [&](int P2) {  // backward: saved pre-activations of chunk pair P2 -> staging, all four pairs (wave wq: pair wq)
     T* dst = stg_base_of(wq, P2 & 1);
-    const long prow0 = (long)blockIdx.x * 128 + wq * 32;
+    const long prow0 = (long)blockIdx.x * (4 * RP) + wq * RP;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NFP; ++it) {
       const int r = it * 8 + f_r;
       const int c = (f_pp ^ (r >> 1)) & 7;
       const long m = prow0 + r;
@@ -667,16 +675,19 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(ChainArgs p) {
   auto flush_pair = [&](int P2, int width) {  // staged chunk pair of pair wq -> global (h forward, dh backward)
     T* G = reinterpret_cast<T*>(p.mid_out);
     const T* src = stg_base_of(wq, P2 & 1);
-    const long prow0 = (long)blockIdx.x * 128 + wq * 32;
-    v8 v[4];
+    const long prow0 = (long)blockIdx.x * (4 * RP) + wq * RP;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const v8*>(src + (it * 8 + f_r) * 64 + f_pp * 8);  // one LDS round trip
+    for (int i0 = 0; i0 < NFP; i0 += 4) {  // four pieces per LDS round trip
+      v8 v[4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int r = it * 8 + f_r;
-      const int c = (f_pp ^ (r >> 1)) & 7;
-      const long m = prow0 + r;
-      if (m < p.M && c * 8 < width) *reinterpret_cast<v8*>(G + m * p.ldm + P2 * 64 + c * 8) = v[it];
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const v8*>(src + ((i0 + u) * 8 + f_r) * 64 + f_pp * 8);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = (i0 + u) * 8 + f_r;
+        const int c = (f_pp ^ (r >> 1)) & 7;
+        const long m = prow0 + r;
+        if (m < p.M && c * 8 < width) *reinterpret_cast<v8*>(G + m * p.ldm + P2 * 64 + c * 8) = v[u];
+      }
     }
   };
 
@@ -690,23 +701,26 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(ChainArgs p) {
       if (nchunks > 2) issue_h(1);
     }
   }
-  // this wave's 16 input rows (row group t of the pair) -> B fragments (row fr, k = ks*32 + g*8 .. +7), resident for the
-  // whole kernel
-  v8 xf[KS];
+  // this wave's 16 TM input rows (row groups t TM .. t TM + TM - 1 of the pair) -> B fragments (row fr of group i,
+  // k = ks*32 + g*8 .. +7), resident for the whole kernel
+  v8 xf[TM][KS];
   {
     const T* A = reinterpret_cast<const T*>(p.a);
-    const long m = row0 + t * 16 + fr;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int k = ks * 32 + g * 8;
-      v8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (m < p.M && k < C) v = *reinterpret_cast<const v8*>(A + m * p.lda + k);
-      xf[ks] = v;
+    for (int i = 0; i < TM; ++i) {
+      const long m = row0 + (t * TM + i) * 16 + fr;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k = ks * 32 + g * 8;
+        v8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (m < p.M && k < C) v = *reinterpret_cast<const v8*>(A + m * p.lda + k);
+        xf[i][ks] = v;
+      }
     }
   }
-  f32x4 acc[2][KS];
+  f32x4 acc[RG][KS];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RG; ++i)
 #pragma unroll
     for (int n = 0; n < KS; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -714,16 +728,17 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(ChainArgs p) {
   asm volatile("" ::: "memory");
   if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one interval behind group 0
 
-  f32x4 d[2];  // GEMM-a result of this wave's row group: hidden units 4g .. 4g+3 (d[0]) and 16 + 4g .. (d[1]) of the chunk
-  v8 own;      // ... after the elementwise middle: exactly one K = 32 B fragment of GEMM-b (k permutation of the weight image)
-  v4 hq[2];    // backward: the saved pre-activations of this lane's 8 hidden units, read from the staging buffer in the MFMA phase
+  f32x4 d[TM][2];  // GEMM-a result of row group i: hidden units 4g .. 4g+3 (d[i][0]) and 16 + 4g .. (d[i][1]) of the chunk
+  v8 own[TM];      // ... after the elementwise middle: exactly one K = 32 B fragment of GEMM-b (k permutation of the weight image)
+  v4 hq[TM][2];    // backward: the saved pre-activations of this lane's 8 hidden units per row group, read in the MFMA phase
   T* exch = lds + OFF_EX;
-  // One MFMA phase = GEMM-b of chunk jb (12 weight fragments, two products each; skipped for jb < 0) and GEMM-a of chunk ja
-  // (2 KS fragments, one product each; skipped for ja < 0), fragments in batches of FB: the reads of a batch are issued before
+  auto exch_at = [&](int par, int tt, int i) { return exch + ((((par * 4 + pair) * 2 + tt) * TM + i) * 512) + lane * 8; };
+  // One MFMA phase = GEMM-b of chunk jb (KS weight fragments, 2 TM products each; skipped for jb < 0) and GEMM-a of chunk ja
+  // (2 KS fragments, TM products each; skipped for ja < 0), fragments in batches of FB: the reads of a batch are issued before
   // the products of the batch in front of it, so only the first batch's LDS latency is exposed (measured: a batch whose reads
   // stand directly in front of its own products costs 200 - 300 cycles of LDS latency per batch with every wave of the group
   // reading at once).  Forward: the chunk's biases are read with the first batch and become GEMM-a's initial accumulators.
-  constexpr int FB = 6;
+  constexpr int FB = TM == 1 ? 6 : (MODE == MODE_BWD ? 3 : 4);  // (32 rows per wave: 16 more registers hold GEMM-b operands - and, backward, the saved pre-activations -, so smaller batches)
   const int b_lane = (fr >> 1) * 64 + ((((fr & 1) * 4 + g) ^ ((fr >> 1) & 7)) << 3);
   const int a_lane[2] = {fr * 64 + ((g ^ (fr & 7)) << 3), fr * 64 + (((4 + g) ^ (fr & 7)) << 3)};
   constexpr int NB_B = (KS + FB - 1) / FB, NB_A = (2 * KS) / FB;  // batches of GEMM-b / GEMM-a
@@ -731,7 +746,7 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(ChainArgs p) {
   auto mfma_phase = [&](auto has_b_c, auto has_a_c, int jb, int ja) __attribute__((always_inline)) {
     constexpr bool HAS_B = decltype(has_b_c)::value, HAS_A = decltype(has_a_c)::value;  // compile-time: the buffer slots are too
     v8 fr_[2][FB];
-    v8 gf[2];
+    v8 gf[RG];
     const T* Wb = lds + OFF_B + (jb & 1) * BEL;
     const T* Wa = lds + OFF_A + (ja & 1) * AEL;
     auto read_b = [&](int bb, int slot) {
@@ -741,7 +756,7 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(ChainArgs p) {
         if (n >= KS) break;
         // row (t KS + n) 16 + fr of the [C / 2][64] view: R = row >> 1 = (t KS + n) 8 + (fr >> 1), R & 7 = fr >> 1, so the
         // swizzled position is a per-lane constant and the fragment address is lane base + 512 n elements (an immediate)
-        if ((ABL & 32) && n > 0) fr_[slot][u] = xf[0];  // timing only: one fragment read per phase
+        if ((ABL & 32) && n > 0) fr_[slot][u] = xf[0][0];  // timing only: one fragment read per phase
         else fr_[slot][u] = *reinterpret_cast<const v8*>(Wb + (t * KS + n) * 512 + b_lane);
       }
     };
@@ -751,7 +766,7 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(ChainArgs p) {
         const int f = ab * FB + u;
         const int ks = f >> 1, tt = f & 1;
         // hidden row h = 16 tt + fr of sub-tile ks >> 1: (h & 7) = fr & 7, so two per-lane constants (k-step parity) + immediates
-        if ((ABL & 32) && f > 0) fr_[slot][u] = xf[0];
+        if ((ABL & 32) && f > 0) fr_[slot][u] = xf[0][0];
         else fr_[slot][u] = *reinterpret_cast<const v8*>(Wa + (ks >> 1) * 2048 + tt * 1024 + a_lane[ks & 1]);
       }
     };
@@ -760,35 +775,46 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(ChainArgs p) {
       for (int u = 0; u < FB; ++u) {
         const int n = bb * FB + u;
         if (n >= KS) break;
-        acc[0][n] = mfma16(fr_[slot][u], gf[0], acc[0][n]);
-        acc[1][n] = mfma16(fr_[slot][u], gf[1], acc[1][n]);
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) acc[rg][n] = mfma16(fr_[slot][u], gf[rg], acc[rg][n]);
       }
     };
     auto mul_a = [&](int ab, int slot) {
 #pragma unroll
       for (int u = 0; u < FB; ++u) {
         const int f = ab * FB + u;
-        d[f & 1] = mfma16(fr_[slot][u], xf[f >> 1], d[f & 1]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) d[i][f & 1] = mfma16(fr_[slot][u], xf[i][f >> 1], d[i][f & 1]);
       }
     };
     if constexpr (HAS_B) {
-      const v8 other = *reinterpret_cast<const v8*>(exch + (((jb & 1) * 4 + pair) * 2 + (1 - t)) * 512 + lane * 8);
       read_b(0, 0);
-      gf[0] = t == 0 ? own : other;
-      gf[1] = t == 0 ? other : own;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {  // row groups t TM + i are this wave's own, the others the partner's
+        const v8 other = *reinterpret_cast<const v8*>(exch_at(jb & 1, 1 - t, i));
+        gf[i] = t == 0 ? own[i] : other;
+        gf[TM + i] = t == 0 ? other : own[i];
+      }
     }
     if constexpr (HAS_A) {
       if constexpr (MODE == MODE_FWD) {
         const float* Ba = reinterpret_cast<const float*>(lds + OFF_BIAS + (ja & 3) * 64);
-        d[0] = *reinterpret_cast<const f32x4*>(Ba + g * 4);
-        d[1] = *reinterpret_cast<const f32x4*>(Ba + 16 + g * 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ba + g * 4), b1 = *reinterpret_cast<const f32x4*>(Ba + 16 + g * 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          d[i][0] = b0;
+          d[i][1] = b1;
+        }
       } else {
-        d[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        d[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int e0 = (ja & 1) * 32 + g * 4;
         const T* stg = stg_base((ja >> 1) & 1);
-        hq[0] = *reinterpret_cast<const v4*>(stg + stg_off(t * 16 + fr, e0));
-        hq[1] = *reinterpret_cast<const v4*>(stg + stg_off(t * 16 + fr, e0 + 16));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          d[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          d[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          hq[i][0] = *reinterpret_cast<const v4*>(stg + stg_off((t * TM + i) * 16 + fr, e0));
+          hq[i][1] = *reinterpret_cast<const v4*>(stg + stg_off((t * TM + i) * 16 + fr, e0 + 16));
+        }
       }
       if constexpr (!HAS_B) read_a(0, 0);
     }
@@ -851,44 +877,45 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(ChainArgs p) {
       }
     } else if (keep_mid && !(ABL & 1) && (j & 1) == 0 && j >= 2) {
       // Group 0 (interval 2 j + 1): chunk pair (j >> 1) - 1 of all four pairs is complete (group 1 wrote its last part in
-      // interval 2 j - 2 ... wait for nothing: the stores stay in flight
+      // interval 2 j - 2); nothing waits for the stores: they stay in flight
       flush_pair((j >> 1) - 1, 64);
     }
     {
       const int e0 = (j & 1) * 32 + g * 4;   // this lane's hidden units e0 .. e0+3 and e0+16 .. e0+19 of the chunk pair's 64
-      const int r = t * 16 + fr;             // its row inside the pair's 32
       T* stg = stg_base((j >> 1) & 1);
-      v4 h0, h1;
-      if constexpr (MODE == MODE_FWD) {
-        h0[0] = (T)d[0][0]; h0[1] = (T)d[0][1]; h0[2] = (T)d[0][2]; h0[3] = (T)d[0][3];  // (the accumulators started from the bias)
-        h1[0] = (T)d[1][0]; h1[1] = (T)d[1][1]; h1[2] = (T)d[1][2]; h1[3] = (T)d[1][3];
-        if (keep_mid) {
-          *reinterpret_cast<v4*>(stg + stg_off(r, e0)) = h0;
-          *reinterpret_cast<v4*>(stg + stg_off(r, e0 + 16)) = h1;
-        }
-        CHAIN_TR_SB(6);
-        // GELU of the stored (rounded) pre-activation: what backward will differentiate
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          own[q] = (ABL & 4) ? h0[q] : (T)gelu_t<T>((float)h0[q]);
-          own[4 + q] = (ABL & 4) ? h1[q] : (T)gelu_t<T>((float)h1[q]);
-        }
-        CHAIN_TR_SB(7);
-      } else {
-        h0 = hq[0];
-        h1 = hq[1];
-        v4 o0, o1;
+      for (int i = 0; i < TM; ++i) {
+        const int r = (t * TM + i) * 16 + fr;  // its row inside the pair
+        v4 h0, h1;
+        if constexpr (MODE == MODE_FWD) {
+          h0[0] = (T)d[i][0][0]; h0[1] = (T)d[i][0][1]; h0[2] = (T)d[i][0][2]; h0[3] = (T)d[i][0][3];  // (accumulators started from the bias)
+          h1[0] = (T)d[i][1][0]; h1[1] = (T)d[i][1][1]; h1[2] = (T)d[i][1][2]; h1[3] = (T)d[i][1][3];
+          if (keep_mid) {
+            *reinterpret_cast<v4*>(stg + stg_off(r, e0)) = h0;
+            *reinterpret_cast<v4*>(stg + stg_off(r, e0 + 16)) = h1;
+          }
+          // GELU of the stored (rounded) pre-activation: what backward will differentiate
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          o0[q] = (T)(d[0][q] * ((ABL & 4) ? (float)h0[q] : dgelu_t<T>((float)h0[q])));
-          o1[q] = (T)(d[1][q] * ((ABL & 4) ? (float)h1[q] : dgelu_t<T>((float)h1[q])));
-          own[q] = o0[q];
-          own[4 + q] = o1[q];
+          for (int q = 0; q < 4; ++q) {
+            own[i][q] = (ABL & 4) ? h0[q] : (T)gelu_t<T>((float)h0[q]);
+            own[i][4 + q] = (ABL & 4) ? h1[q] : (T)gelu_t<T>((float)h1[q]);
+          }
+        } else {
+          h0 = hq[i][0];
+          h1 = hq[i][1];
+          v4 o0, o1;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            o0[q] = (T)(d[i][0][q] * ((ABL & 4) ? (float)h0[q] : dgelu_t<T>((float)h0[q])));
+            o1[q] = (T)(d[i][1][q] * ((ABL & 4) ? (float)h1[q] : dgelu_t<T>((float)h1[q])));
+            own[i][q] = o0[q];
+            own[i][4 + q] = o1[q];
+          }
+          *reinterpret_cast<v4*>(stg + stg_off(r, e0)) = o0;  // in place: dh over h
+          *reinterpret_cast<v4*>(stg + stg_off(r, e0 + 16)) = o1;
         }
-        *reinterpret_cast<v4*>(stg + stg_off(r, e0)) = o0;  // in place: dh over h
-        *reinterpret_cast<v4*>(stg + stg_off(r, e0 + 16)) = o1;
+        *reinterpret_cast<v8*>(exch_at(j & 1, t, i)) = own[i];
       }
-      *reinterpret_cast<v8*>(exch + (((j & 1) * 4 + pair) * 2 + t) * 512 + lane * 8) = own;
     }
     if constexpr (CHAIN_PRIO == 2) __builtin_amdgcn_s_setprio(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -911,8 +938,8 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(ChainArgs p) {
   __builtin_amdgcn_s_barrier();    // nobody reads the weight rings or the staging buffers any more
   asm volatile("" ::: "memory");
 
-  // ---- epilogue: this wave's 32 rows x 16 KS columns through a per-wave LDS tile, then whole 16-byte row pieces
-  T* ep = lds + wave * (32 * PE);
+  // ---- epilogue: the pair's RP rows x this wave's 16 KS columns through a per-wave LDS tile, then whole 16-byte row pieces
+  T* ep = lds + wave * (RP * PE);
   const int col0 = t * KS * 16;
 #pragma unroll
   for (int n = 0; n < KS; ++n) {
@@ -922,7 +949,7 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(ChainArgs p) {
       if (col0 + col < C) b2 = *reinterpret_cast<const float4*>(p.bias_b + col0 + col);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RG; ++i) {
       v4 zq;
       zq[0] = (T)(acc[i][n][0] + b2.x);
       zq[1] = (T)(acc[i][n][1] + b2.y);
@@ -941,7 +968,7 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(ChainArgs p) {
     for (int q = 0; q < 8; ++q) cs[q] = 0.f;
     if constexpr (MODE == MODE_FWD) load8(p.colscale + gcol, cs);
 #pragma unroll 4
-    for (int r = rsub; r < 32; r += RPI) {
+    for (int r = rsub; r < RP; r += RPI) {
       const long m = row0 + r;
       if (m >= p.M) break;
       const v8 zq = *reinterpret_cast<const v8*>(ep + r * PE + piece * 8);
@@ -999,7 +1026,7 @@ static int launch_chain(const ChainArgs& a, hipStream_t st) {
       // 256 < C <= 384: the pair-split kernel (two 256-register waves per SIMD); VKAS_CHAIN_PAIR=0 keeps the one-wave form
       if (a.C % 16 == 0 && chain_pair_mode() != 0) {
         const unsigned grid = (unsigned)vkas_cdiv(a.M, 128);
-        mlp_chain_pair_kernel<T, 12, MODE><<<grid, 512, 0, st>>>(a);
+        mlp_chain_pair_kernel<T, 12, 1, MODE><<<grid, 512, 0, st>>>(a);
       } else {
         VKAS_CHAIN(12, 2, 1)
       }

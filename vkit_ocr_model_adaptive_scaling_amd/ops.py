@@ -1348,7 +1348,7 @@ class ConvNextLayer(Function):
             g = None
             img = pack_mlp_chain(w1, w2, b1, C, 0, x.dtype)
             es = x.element_size()
-            _timed('mlp_chain_kernel<fwd>', x, 4.0 * M * C * C4, M, C, C4,
+            _timed('mlp_chain_pair_kernel<fwd>' if 256 < C <= 384 else 'mlp_chain_kernel<fwd>', x, 4.0 * M * C * C4, M, C, C4,
                    lambda: check(lib.vkas_mlp_chain_fwd(_p(yn), Cp, _p(img), _p(pad_vector(b2, Cp)),
                                                         _p(x), act_ld(x), _p(cs), _p(rs), H * W, _p(h), C4p, _p(z), Cp,
                                                         _p(out), Cp, M, C, dt, st), 'mlp_chain_fwd'),
@@ -1406,7 +1406,7 @@ class ConvNextLayer(Function):
             dh = new_act(B, H, W, C4p, x)
             dyn = new_act(B, H, W, Cp, x)
             imgt = pack_mlp_chain(w1, w2, None, C, 1, x.dtype)
-            _timed('mlp_chain_kernel<bwd>', x, 4.0 * M * C * C4, M, C, C4,
+            _timed('mlp_chain_pair_kernel<bwd>' if 256 < C <= 384 else 'mlp_chain_kernel<bwd>', x, 4.0 * M * C * C4, M, C, C4,
                    lambda: check(lib.vkas_mlp_chain_bwd(_p(dz), Cp, _p(imgt), _p(h), C4p, _p(dh), C4p, _p(dyn), Cp, M, C,
                                                         dt, st), 'mlp_chain_bwd'),
                    float(M) * (2 * Cp + 2 * C4p) * x.element_size())
