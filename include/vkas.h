@@ -42,7 +42,7 @@ extern "C" {
 
 /* GEMM epilogues (vkas_conv_gemm_fwd) */
 #define VKAS_EPI_NONE 0       /* out = acc + bias */
-#define VKAS_EPI_GELU 1       /* out = acc + bias (pre-activation), out2 = gelu(out)         helper.py:100 */
+#define VKAS_EPI_GELU 1       /* out = acc + bias (pre-activation; NULL = not kept), out2 = gelu(out)  helper.py:100 */
 #define VKAS_EPI_SCALE_RES 2  /* out2 = acc + bias; out = aux + rowscale[b]*colscale[n]*out2  convnext.py:56-58 */
 #define VKAS_EPI_DGELU 3      /* out = (acc) * gelu'(aux)                                     backward of helper.py:100 */
 #define VKAS_EPI_ADD 4        /* out = acc + bias + aux                                       gradient accumulation */

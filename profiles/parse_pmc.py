@@ -22,10 +22,13 @@ def short(name):
     m = re.search(r'(conv3x3_slab_mfma_kernel)ILi(\d)ELb(\d)E', name)
     if m:
         return f'{m.group(1)}<{m.group(2)},{m.group(3)}>'
+    m = re.search(r'(gemm_nt_ring_kernel)ILi(\d)E', name)
+    if m:
+        return f'{m.group(1)}<{m.group(2)}>'
     m = re.search(r'(conv3x3_wgrad_slab_kernel)ILi(\d)E', name)
     if m:
         return f'{m.group(1)}<{m.group(2)}>'
-    m = re.search(r'mlp_chain_pair_kernelI\w+?Li\d+ELi(\d)E', name)
+    m = re.search(r'mlp_chain_pair_kernelI\w+?Li\d+ELi\d+ELi(\d)E', name)
     if m:
         return 'mlp_chain_pair_kernel<fwd>' if m.group(1) == '0' else 'mlp_chain_pair_kernel<bwd>'
     m = re.search(r'mlp_chain_kernelI\w+?Li\d+ELi\d+ELi(\d)ELi\d+E', name)

@@ -176,6 +176,56 @@ torch.save({'y': y.float().cpu(), 'gx': x.grad.float().cpu(), 'gw': w.grad.cpu()
         assert rel_err(outs[0][k], outs[1][k]) < 3e-3, k
 
 
+def test_ring_kernel_matches_register_staged_kernel_bitwise():
+    """gemm_nt_ring_kernel (launches of few tiles: LDS-DMA ring) against gemm_nt_mfma_kernel<2,2,4,4> in a second process with
+    VKAS_NT_RING=0: same geometry decode, K order and epilogue, so the outputs are bit-identical - pointwise shapes with M / N / K
+    tails, a 3x3 im2col geometry with padding, a strided patchify, ring depths 2 and 4, and the no-grad layer path that drops
+    the pre-activation."""
+    import os, subprocess, sys, tempfile
+    code = r'''
+import torch, sys
+from vkit_ocr_model_adaptive_scaling_amd import ops, _lib
+g = torch.Generator().manual_seed(9)
+out = {}
+for i, (B, H, W, C, N, k, s, p) in enumerate([(1, 37, 29, 520, 136, 1, 1, 0), (2, 40, 40, 384, 1536, 1, 1, 0),
+                                               (1, 20, 28, 96, 40, 3, 1, 1), (1, 32, 24, 96, 192, 2, 2, 0)]):
+    x = torch.randn((B, H, W, C), generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn((N, C, k, k), generator=g) * 0.03).cuda()
+    b = torch.randn((N,), generator=g).cuda()
+    with torch.no_grad():
+        out['conv%d' % i] = ops.Conv.apply(x, w, b, s, p).float().cpu()
+C = 320
+x = torch.randn((1, 12, 16, C), generator=g).to(torch.bfloat16).cuda()
+ps = [torch.randn(C, 1, 7, 7, generator=g) * 0.15, torch.randn(C, generator=g) * 0.1, torch.ones(C), torch.zeros(C),
+      torch.randn(4 * C, C, generator=g) / C ** 0.5, torch.randn(4 * C, generator=g) * 0.1,
+      torch.randn(C, 4 * C, generator=g) * 0.5 / C ** 0.5, torch.randn(C, generator=g) * 0.1, torch.ones(C, 1, 1)]
+ps = [t.cuda() for t in ps]
+with torch.no_grad():
+    out['layer_nograd'] = ops.ConvNextLayer.apply(x, *ps, None, False).float().cpu()
+out['layer_keep'] = ops.ConvNextLayer.apply(x, *ps, None, True).float().cpu()
+geom = _lib.ConvGeom(1, 12, 16, 12, 16, C, C, 1, 1, 1, 0)
+out['kid'] = torch.tensor([_lib.lib.vkas_conv_gemm_kernel_id(0, __import__('ctypes').byref(geom), 4 * C, 0, 0)])
+torch.save(out, sys.argv[1])
+'''
+    outs = {}
+    for ring in ('0', '2', '4', ''):
+        with tempfile.NamedTemporaryFile(suffix='.pt') as f:
+            env = dict(os.environ)
+            env.pop('VKAS_NT_RING', None)
+            if ring:
+                env['VKAS_NT_RING'] = ring
+            subprocess.run([sys.executable, '-c', code, f.name], check=True, env=env,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            outs[ring] = torch.load(f.name, weights_only=True)
+    assert int(outs['0']['kid']) == 1 and int(outs['2']['kid']) == 12 and int(outs['4']['kid']) == 14 and int(outs['']['kid']) in (12, 14)
+    for ring in ('2', '4', ''):
+        for k, v in outs['0'].items():
+            if k != 'kid':
+                assert torch.equal(v, outs[ring][k]), (ring, k, rel_err(v, outs[ring][k]))
+    # dropping the pre-activation (and z) changes nothing in what the layer returns
+    assert torch.equal(outs['']['layer_nograd'], outs['']['layer_keep'])
+
+
 # --------------------------------------------------------------------------------------------- dwconv / layer
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('shape', [(2, 24, 19, 37), (1, 16, 8, 8), (2, 96, 40, 33), (1, 40, 5, 3),
@@ -235,10 +285,11 @@ def test_mlp_chain_matches_two_gemm_path(C):
     mask = torch.tensor([1.25, 0.0, 1.0], device='cuda')
     cot = torch.randn(B, H, W, C, device='cuda').to(torch.bfloat16)
     res = {}
-    max_c = ops._CHAIN_MAX_C
+    max_c, min_rows = ops._CHAIN_MAX_C, ops._CHAIN_PAIR_MIN_ROWS
     for chain in (True, False):
         ops._NO_CHAIN = not chain
         ops._CHAIN_MAX_C = 512  # the wide instantiations are not the default path (no faster than two GEMMs)
+        ops._CHAIN_PAIR_MIN_ROWS = 0  # nor is the pair-split kernel at this few rows
         try:
             ps = [t.clone().cuda().requires_grad_(True) for t in base]
             xa = x.clone().requires_grad_(True)
@@ -249,6 +300,7 @@ def test_mlp_chain_matches_two_gemm_path(C):
         finally:
             ops._NO_CHAIN = False
             ops._CHAIN_MAX_C = max_c
+            ops._CHAIN_PAIR_MIN_ROWS = min_rows
     for name, a, b in zip(['out', 'dx'] + names, res[True], res[False]):
         assert rel_err(a, b) < 1.5e-2, (name, rel_err(a, b))
     assert float(res[True][0][1].float().sub(x[1].float()).abs().max()) == 0.0, 'dropped sample must pass through'

@@ -14,6 +14,7 @@ int vkas_gemm_tn_mfma_f16(const void*, const vkas_conv_geom*, const void*, long,
 int vkas_gemm_nt_tile_choice(long M, int Np);
 int vkas_gemm_tn_tile_choice(long M, int Np, int K);
 bool vkas_nt_slab_eligible(const vkas_conv_geom* g, int Np);
+int vkas_gemm_nt_ring_stages(const vkas_conv_geom* g, int Np);
 bool vkas_tn_slab_eligible(const vkas_conv_geom* g, int Np, long lddy);
 bool vkas_tn_slab_n112(int Np);
 bool vkas_tn_slab_n96(int Np);
@@ -57,7 +58,7 @@ int vkas_check_geom(const char* who, const void* x, const vkas_conv_geom* g, int
 
 int vkas_check_epilogue(const char* who, const vkas_epilogue* e, int Np) {
   // the fused head tail may run without z / statistics outputs (inference: nothing is kept for a backward pass)
-  VKAS_CHECK(e && (e->out || e->mode == VKAS_EPI_HEAD), "%s: null output", who);
+  VKAS_CHECK(e && (e->out || e->mode == VKAS_EPI_HEAD || (e->mode == VKAS_EPI_GELU && e->out2)), "%s: null output", who);
   VKAS_CHECK(vkas_aligned16(e->out) && e->ldo % 8 == 0, "%s: out misaligned (ldo=%ld)", who, e->ldo);
   VKAS_CHECK(e->mode >= VKAS_EPI_NONE && e->mode <= VKAS_EPI_HEAD, "%s: bad epilogue mode %d", who, e->mode);
   if (e->mode == VKAS_EPI_HEAD) {
@@ -112,7 +113,8 @@ extern "C" int vkas_conv_gemm_tile(int wgrad, long M, int Np, int K) {
   return wgrad ? vkas_gemm_tn_tile_choice(M, Np, K) : vkas_gemm_nt_tile_choice(M, Np);
 }
 
-// Which kernel a bf16 call with this geometry runs: 0 plain fp32-FMA kernels forced; fwd: 1 = 128x128, 128 / 192 / 224 =
+// Which kernel a bf16 call with this geometry runs: 0 plain fp32-FMA kernels forced; fwd: 1 = 128x128, 12 / 13 / 14 =
+// gemm_nt_ring_kernel<2 / 3 / 4>, 128 / 192 / 224 =
 // N extent of the generic 256-row tile, 1000 + TN = conv3x3_slab_mfma_kernel<TN, .> (TN = 4, 6, 7); wgrad: 128 / 192 /
 // 224 generic, 2000 + TNn = conv3x3_wgrad_slab_kernel<TNn>.  head_width > 0: a fused-head launch whose widest head has
 // that many columns.
@@ -127,6 +129,7 @@ extern "C" int vkas_conv_gemm_kernel_id(int wgrad, const vkas_conv_geom* g, int 
   int choice = vkas_gemm_nt_tile_choice(M, Np);
   if (head_width > 0) choice = head_width <= 128 ? 128 : (head_width <= 192 ? 192 : 224);
   if (choice != 1 && vkas_nt_slab_eligible(g, Np)) return 1000 + choice / 32;
+  if (choice == 1 && head_width <= 0 && vkas_gemm_nt_ring_stages(g, Np) > 0) return 10 + vkas_gemm_nt_ring_stages(g, Np);
   return choice;
 }
 

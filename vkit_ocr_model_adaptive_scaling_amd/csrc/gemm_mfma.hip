@@ -36,6 +36,7 @@ typedef bf16x4 elem4;
 int vkas_gemm_nt_tile_choice(long M, int Np);
 int vkas_gemm_tn_tile_choice(long M, int Np, int K);
 bool vkas_nt_slab_eligible(const vkas_conv_geom* g, int Np);
+int vkas_gemm_nt_ring_stages(const vkas_conv_geom* g, int Np);
 bool vkas_tn_slab_eligible(const vkas_conv_geom* g, int Np, long lddy);
 bool vkas_tn_slab_n112(int Np);
 bool vkas_tn_slab_n96(int Np);
@@ -529,6 +530,154 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_mfma_kernel(const elem_t*
     vkas_trace_buf[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
   }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gemm_nt_ring_kernel (round 4): the NT GEMM for launches of FEW tiles - the forward-only configurations of BASELINE.json
+// (configs[1] / [4]: one to four pages per call, M = 400 ... 12 288 rows at stages 2 / 3 of the backbone, K up to 4 096).
+// There a launch is one round of <= 256 workgroups and its duration is the length of ONE workgroup's K loop; the kernel above
+// requests a K tile one and a half iterations ahead through registers, so every iteration costs most of a memory round trip
+// (1.1 us per 64-deep step measured: 70 us for M = 1 792, N = 1 024, K = 4 096 - profiles/sweep_small.py).  This kernel keeps
+// NST - 1 K tiles in flight instead: operands go global -> LDS by LDS-DMA into a ring of NST stages (no staging registers, no
+// ds_write pass), a stage is waited for with a counted vmcnt (the younger stages stay in flight) in front of ONE raw barrier per
+// K tile, and the slot read in the previous iteration is refilled right behind that barrier.  128 x 128 tile, 8 waves of 32 x 64
+// (two per SIMD, so one wave's requests and fragment reads sit behind the other's MFMAs); same geometry decode, swizzle, MFMA
+// operand order and epilogue as gemm_nt_mfma_kernel - the results are bit-identical to it.
+// LDS image: a wave instruction fills 8 rows x 128 B, lane-linear; the XOR swizzle the fragment reads expect is applied to the
+// per-lane SOURCE chunk (as in the slab kernel).  Out-of-range lanes (zero padding, M / N / K tails, the dummy stages behind the
+// last K tile that keep the wait count uniform) use an offset beyond the descriptor: the hardware writes zeros.
+template <int NST>
+__global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const elem_t* __restrict__ x, vkas_conv_geom g,
+                                                           const elem_t* __restrict__ Bw, int Np, long M, int K,
+                                                           vkas_epilogue e, unsigned a_bytes, unsigned b_bytes) {
+  constexpr int WM = 4, WN = 2, TM = 2, TN = 4;
+  constexpr int NTHR = WM * WN * 64;
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int RSTEP = NTHR / 8;                     // rows covered by one staging instruction of every wave
+  constexpr int ACH = BM / RSTEP, BCH = BN / RSTEP;   // requests per lane and stage
+  constexpr int STAGE = (BM + BN) * BK;               // elements per ring stage
+  static_assert(BM % RSTEP == 0 && BN % RSTEP == 0 && RSTEP % 8 == 0, "whole 8-row instructions");
+  static_assert(NST >= 2 && NST * STAGE * 2 <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(1024))) elem_t lds[NST * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const unsigned ntile_n = (unsigned)((Np + BN - 1) / BN);
+  const unsigned total = gridDim.x;
+  const unsigned xcd = blockIdx.x & 7u, slot8 = blockIdx.x >> 3;
+  const unsigned q8 = total >> 3, r8 = total & 7u;
+  const unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
+  const long m0 = (long)(tile / ntile_n) * BM;
+  const int tile_n = (int)(tile % ntile_n);
+  const int n0 = tile_n * BN;
+  const int n_end = Np;
+
+  // staging role: LDS position (tid & 7) of rows sr + RSTEP i; it receives source chunk cc = position ^ (row & 7)
+  const int sr = tid >> 3;
+  const int cc = (tid & 7) ^ (sr & 7);
+  int a_by[ACH], a_y[ACH], a_x[ACH];
+  unsigned a_base[ACH], b_base[BCH];
+  bool b_ok[BCH];
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) {
+    const RowCoord rc = decode_row(m0 + sr + RSTEP * i, M, g);
+    a_by[i] = rc.ok ? rc.b * g.Hin : -1;
+    a_y[i] = rc.oy * g.stride - g.pad;
+    a_x[i] = rc.ox * g.stride - g.pad;
+    a_base[i] = (((unsigned)(rc.b * g.Hin + a_y[i]) * (unsigned)g.Win + (unsigned)a_x[i]) * (unsigned)g.ldx) << 1;
+  }
+#pragma unroll
+  for (int i = 0; i < BCH; ++i) {
+    const int n = n0 + sr + RSTEP * i;
+    b_ok[i] = n < n_end;
+    b_base[i] = ((unsigned)(b_ok[i] ? n : 0) * (unsigned)K) << 1;
+  }
+  int kcur = cc * 8;
+  int c_in = kcur, ky = 0, kx = 0;
+  while (c_in >= g.Cp) {
+    c_in -= g.Cp;
+    if (++kx == g.KW) { kx = 0; ++ky; }
+  }
+  const u32x4 rs_a = vkas_make_rsrc(x, a_bytes);
+  const u32x4 rs_b = vkas_make_rsrc(Bw, b_bytes);
+  const unsigned lds0 = vkas_lds_addr(lds) + (unsigned)wave * (8 * BK * 2);  // this wave's 8 rows of staging pass 0
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  auto issue = [&](int slot) __attribute__((always_inline)) {
+    const bool k_ok = kcur < K;
+    const unsigned t_off = (((unsigned)(ky * g.Win + kx) * (unsigned)g.ldx) + (unsigned)c_in) << 1;
+    const unsigned dst = lds0 + (unsigned)slot * (STAGE * 2);
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+      const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+      const bool ok = k_ok && a_by[i] >= 0 && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+      vkas_lds_dma16(rs_a, dst + i * (RSTEP * BK * 2), ok ? a_base[i] + t_off : OOB);
+    }
+    const unsigned kb2 = (unsigned)kcur << 1;
+#pragma unroll
+    for (int i = 0; i < BCH; ++i)
+      vkas_lds_dma16(rs_b, dst + BM * BK * 2 + i * (RSTEP * BK * 2), (k_ok && b_ok[i]) ? b_base[i] + kb2 : OOB);
+    kcur += BK;
+    c_in += BK;
+    if (g.Cp >= BK) {  // wave-uniform
+      const bool wrap = c_in >= g.Cp;
+      c_in -= wrap ? g.Cp : 0;
+      kx += wrap ? 1 : 0;
+      const bool wrap_x = kx == g.KW;
+      kx = wrap_x ? 0 : kx;
+      ky += wrap_x ? 1 : 0;
+    } else {
+      while (c_in >= g.Cp) {
+        c_in -= g.Cp;
+        if (++kx == g.KW) { kx = 0; ++ky; }
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (K + BK - 1) / BK;
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) issue(s);
+
+  const int frow = lane & 15;
+  const int fchunk = lane >> 4;
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // K tile kt has landed once at most the NST - 2 younger stages of this wave are outstanding; behind the barrier every
+    // wave's share of it is visible and every wave has finished reading tile kt - 1, whose slot is refilled at once
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (ACH + BCH)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    // the two waves of a SIMD (w and w + 4) take turns: one issues its requests while the other one multiplies
+    if (wave < 4) issue(slot == 0 ? NST - 1 : slot - 1);
+    const elem_t* As = lds + slot * STAGE;
+    const elem_t* Bs = As + BM * BK;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      elem8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const elem8*>(As + swz_off(wm * TM * 16 + i * 16 + frow, s * 4 + fchunk));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = *reinterpret_cast<const elem8*>(Bs + swz_off(wn * TN * 16 + j * 16 + frow, s * 4 + fchunk));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = VKAS_MFMA16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    if (wave >= 4) issue(slot == 0 ? NST - 1 : slot - 1);
+    slot = slot + 1 == NST ? 0 : slot + 1;
+  }
+  // the dummy stages (zero fill) must have landed and every wave must be done reading before the ring becomes epilogue staging
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  nt_epilogue<WM, WN, TM, TN, false>(acc, reinterpret_cast<float*>(lds), e, tile_n, m0, M, n0, n_end, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1447,6 +1596,23 @@ int vkas_gemm_nt_tile_choice(long M, int Np) {
   return bn;
 }
 
+// Ring depth of gemm_nt_ring_kernel for a launch the tile choice above gives the 128 x 128 tile (0 = the register-staged
+// kernel).  At most one round of workgroups (<= 256 tiles): four stages (128 KB of LDS, one workgroup per CU, three K tiles in
+// flight) - the launch lasts as long as one workgroup's K loop; more tiles: two stages, so that two workgroups share a CU and
+// one's prologue / epilogue sits behind the other's K loop (profiles/sweep_small.py: 4 stages 26.6 / 37.1 us against 31.7 /
+// 52.1 at M = 7 168, N = 512, K = 2 048 / M = 1 792, N = 1 024, K = 4 096; 2 stages 34.2 against 44.3 at M = 7 168,
+// N = 2 048, K = 512; the register-staged kernel: 42.2, 70.2 and 40.0).  VKAS_NT_RING = 0 keeps the register-staged kernel,
+// 2 / 3 / 4 force a depth.
+int vkas_gemm_nt_ring_stages(const vkas_conv_geom* g, int Np) {
+  static const int ring_env = getenv("VKAS_NT_RING") ? atoi(getenv("VKAS_NT_RING")) : -1;
+  const long M = (long)g->B * g->Hout * g->Wout;
+  const long K = (long)g->KH * g->KW * g->Cp;
+  const long a_bytes = (((long)g->B * g->Hin * g->Win - 1) * g->ldx + g->Cp) * 2;
+  if (a_bytes >= 0xFFFFFFF0L || (long)Np * K * 2 >= 0xFFFFFFF0L) return 0;  // operands addressed with 32-bit buffer offsets
+  if (ring_env >= 0) return ring_env >= 2 && ring_env <= 4 ? ring_env : 0;
+  return vkas_cdiv(M, 128) * vkas_cdiv(Np, 128) <= 256 ? 4 : 2;
+}
+
 static bool row_aligned_3x3(const vkas_conv_geom* g, int wmod) {
   return g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1 && g->Hout == g->Hin && g->Wout == g->Win &&
          g->Win % wmod == 0;
@@ -1516,7 +1682,20 @@ int VKAS_MFMA_FN(vkas_gemm_nt_mfma)(const void* x, const vkas_conv_geom* g, cons
     VKAS_LAUNCH_CHECK("conv3x3_slab_mfma");
     return VKAS_OK;
   }
-  if (!big) launch_nt<2, 2, 4, 4>(x, g, Bw, Np, M, K, e, st);
+  if (!big) {
+    const int nst = e->mode == VKAS_EPI_HEAD ? 0 : vkas_gemm_nt_ring_stages(g, Np);
+    if (nst >= 2) {
+      dim3 grid((unsigned)(vkas_cdiv(M, 128) * vkas_cdiv(Np, 128)));
+      const elem_t* xp = (const elem_t*)x;
+      const elem_t* bp = (const elem_t*)Bw;
+      if (nst == 2) gemm_nt_ring_kernel<2><<<grid, 512, 0, st>>>(xp, *g, bp, Np, M, K, *e, (unsigned)a_bytes, (unsigned)b_bytes);
+      else if (nst == 3) gemm_nt_ring_kernel<3><<<grid, 512, 0, st>>>(xp, *g, bp, Np, M, K, *e, (unsigned)a_bytes, (unsigned)b_bytes);
+      else gemm_nt_ring_kernel<4><<<grid, 512, 0, st>>>(xp, *g, bp, Np, M, K, *e, (unsigned)a_bytes, (unsigned)b_bytes);
+      VKAS_LAUNCH_CHECK("gemm_nt_ring");
+      return VKAS_OK;
+    }
+    launch_nt<2, 2, 4, 4>(x, g, Bw, Np, M, K, e, st);
+  }
   else if (bn == 224) launch_nt<4, 2, 4, 7>(x, g, Bw, Np, M, K, e, st);
   else if (bn == 192) launch_nt<4, 2, 4, 6>(x, g, Bw, Np, M, K, e, st);
   else launch_nt<4, 2, 4, 4>(x, g, Bw, Np, M, K, e, st);

@@ -46,7 +46,7 @@ __device__ __forceinline__ void epi_store4(const vkas_epilogue& e, long m, int n
       store4(out + m * e.ldo + n, v);
       break;
     case VKAS_EPI_GELU: {
-      store4(out + m * e.ldo + n, v);
+      if (out) store4(out + m * e.ldo + n, v);  // the pre-activation is only kept for a backward pass
       float gv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) gv[i] = gelu_t<T>(v[i]);
@@ -118,7 +118,7 @@ __device__ __forceinline__ void epi_store8(const vkas_epilogue& e, long m, int n
       break;
     case VKAS_EPI_GELU: {
 #if (VKAS_ABL & 128) == 0
-      store8(out + m * e.ldo + n, v);
+      if (out) store8(out + m * e.ldo + n, v);  // the pre-activation is only kept for a backward pass
 #endif
       float gv[8];
 #pragma unroll

@@ -280,8 +280,16 @@ def _chain_width_ok(C: int) -> bool:
     return C <= min(_CHAIN_MAX_C, 256) or (256 < C <= min(_CHAIN_MAX_C, 384) and C % 16 == 0) or (384 < C <= _CHAIN_MAX_C)
 
 
+# The pair-split kernel walks the 4C hidden units of its 128 rows serially (48 chunks at C = 384: 85 us however few rows there
+# are); below this many rows - the forward-only configurations, M = 6 400 at stage 2 of config #2 - the two ring GEMMs
+# (csrc/gemm_mfma.hip::gemm_nt_ring_kernel: 25 + 20 us) are faster.
+_CHAIN_PAIR_MIN_ROWS = int(os.environ.get('VKAS_MLP_CHAIN_PAIR_MIN_ROWS', '16384'))
+
+
 def mlp_chain_eligible(x: torch.Tensor, C: int) -> bool:
     """The fused ConvNeXt MLP kernels (csrc/mlp_chain.hip) cover 16-bit activations with C % 8 == 0, C <= 512."""
+    if 256 < C <= 384 and x.shape[0] * x.shape[1] * x.shape[2] < _CHAIN_PAIR_MIN_ROWS:
+        return False
     return (not _NO_CHAIN and x.dtype in _MFMA_DTYPES and x.shape[3] == C and _chain_width_ok(C)
             and lib.vkas_mlp_chain_image_elems(C) > 0)
 
@@ -356,6 +364,8 @@ def nt_kernel_name(kid: int, head: bool) -> str:
         return 'gemm_nt_simple'
     if kid >= 1000:
         return 'conv3x3_slab_mfma_kernel<%d,%d>' % (kid - 1000, int(head))
+    if 12 <= kid <= 14:
+        return 'gemm_nt_ring_kernel<%d>' % (kid - 10)
     return 'gemm_nt_mfma_kernel<%s>' % {1: '2,2,4,4', 128: '4,2,4,4', 192: '4,2,4,6', 224: '4,2,4,7'}[kid]
 
 
@@ -393,7 +403,7 @@ def conv_gemm(x: torch.Tensor, geom: ConvGeom, Bw: torch.Tensor, Np: int, out: t
         else:
             kind = 'gemm_nt_simple'
         es = x.element_size()
-        nbytes = (geom.B * geom.Hin * geom.Win * geom.Cp + M * Np * (1 + (out2 is not None) + (aux is not None))) * es
+        nbytes = (geom.B * geom.Hin * geom.Win * geom.Cp + M * Np * ((out is not None) + (out2 is not None) + (aux is not None))) * es
         return _timed(kind, x, 2.0 * M * N * K, M, N, K,
                       lambda: _conv_gemm(x, geom, Bw, Np, out, mode, bias, out2, aux, colscale, rowscale, rows_per_image,
                                          patch, patch_hw, patch_Cp, head), nbytes)
@@ -1356,7 +1366,9 @@ class ConvNextLayer(Function):
             if not keep:
                 return out
         else:
-            h = new_act(B, H, W, C4p, x)
+            h = new_act(B, H, W, C4p, x) if keep else None  # inference: the pre-activation and z are not written
+            if not keep:
+                z = None
             g = new_act(B, H, W, C4p, x)
             g1 = _geom(B, H, W, H, W, Cp, Cp, 1, 1, 1, 0)
             conv_gemm(yn, g1, pack_conv_weight(w1, C4p, Cp, 0, x.dtype), C4p, h, _lib.EPI_GELU, bias=pad_vector(b1, C4p),
@@ -1364,6 +1376,8 @@ class ConvNextLayer(Function):
             g2 = _geom(B, H, W, H, W, C4p, C4p, 1, 1, 1, 0)
             conv_gemm(g, g2, pack_conv_weight(w2, Cp, C4p, 0, x.dtype), Cp, out, _lib.EPI_SCALE_RES,
                       bias=pad_vector(b2, Cp), out2=z, aux=x, colscale=cs, rowscale=rs, rows_per_image=H * W)
+            if not keep:
+                return out
         empty = torch.empty(0, device=x.device)
         ctx.save_for_backward(x, y, stats, yn, h, g if g is not None else empty, z, dw_w, ln_g, ln_b, w1, w2, block_scale,
                               rs if rs is not None else empty, b1, dw_b, b2)
