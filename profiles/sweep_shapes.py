@@ -81,8 +81,9 @@ if which in ('tn', 'both'):
         gw = torch.zeros((N * K + N,), device='cuda')
         geom = _lib.ConvGeom(1, M // W, W, M // W, W, C, C, KH, KH, 1, KH // 2)
         def run():
-            rc = lib.vkas_conv_gemm_wgrad(x.data_ptr(), ctypes.byref(geom), dy.data_ptr(), N, N, gw.data_ptr(),
-                                          gw.data_ptr() + 4 * N * K, _lib.BF16, st)
+            fn = lib.vkas_conv_gemm_wgrad_gelu if os.environ.get('SWEEP_XG') else lib.vkas_conv_gemm_wgrad
+            rc = fn(x.data_ptr(), ctypes.byref(geom), dy.data_ptr(), N, N, gw.data_ptr(),
+                                          None if os.environ.get('SWEEP_NOBIAS') else gw.data_ptr() + 4 * N * K, _lib.BF16, st)
             assert rc == 0
         ms = timed(run)
         print(f'{tag} TN M={M:7d} N={N:5d} K={K:5d} tile={lib.vkas_conv_gemm_tile(1, M, N, K):4d} {ms * 1e3:8.1f} us '

@@ -966,6 +966,19 @@ __global__ __launch_bounds__(512) void conv3x3_slab_mfma_kernel(const elem_t* __
 // ---------------------------------------------------------------------------------------------------
 constexpr int TN_ROWS = 64;  // reduction rows per iteration
 
+// acc + lo + hi of a packed pair of 16-bit elements (one v_dot2c_f32_{bf16,f16} against (1, 1); products with 1 are exact)
+__device__ __forceinline__ float dot2_ones(unsigned pair, float acc) {
+#ifdef VKAS_MFMA_F16
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, pair), one, acc, false);
+#else
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  const b2 one = {(__bf16)1.0f, (__bf16)1.0f};
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, pair), one, acc, false);
+#endif
+}
+
 // k-permuted transposed fragment: elements 0..3 <- rows mbase + 4g + {0..3}, elements 4..7 <- rows mbase + 16 + 4g + {0..3}
 // (the same permutation is used for both MFMA operands, so the sum over k is unchanged)
 template <int LD>
@@ -987,7 +1000,11 @@ __device__ __forceinline__ elem8 tr_frag(const elem_t* tile, int mbase, int colb
 // read sit on distinct bank groups).
 // XG: the x operand is gelu(x) (the W2 weight gradient of the fused ConvNeXt MLP, whose forward keeps only the
 // pre-activation): applied to the staged registers on their way into LDS, once per element and N tile.
-template <int WN, int WK, int TNn, int TK, bool BUF, bool XG>
+// PW (pointwise, BUF only): KH = KW = 1, stride 1, no padding - row m of x starts at m * ldx, so the per-chunk tap / row
+// decode (and the registers it keeps: three per staged x row) reduce to one running byte offset per staged row.
+// NOBIAS: compiled without the bias-gradient sums (gb must be null): the second staging set only fits beside 96 accumulator
+// registers without them.
+template <int WN, int WK, int TNn, int TK, bool BUF, bool XG, bool PW = false, bool NOBIAS = false>
 __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const elem_t* __restrict__ x, vkas_conv_geom g,
                                                                   const elem_t* __restrict__ dy, long lddy, int Np,
                                                                   long M, int K, long rows_per_split,
@@ -1018,11 +1035,11 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const elem_t*
   const unsigned q8 = total >> 3, r8 = total & 7u;
   const unsigned work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
   const unsigned tile = work % (ntn * ntk);
-  const int n0 = (int)(tile % ntn) * BNn;
-  const int kb = (int)(tile / ntn) * BKc;
-  const bool first_k_tile = tile / ntn == 0;
   const long mbeg = (long)(work / (ntn * ntk)) * rows_per_split;
   const long mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
+  const bool first_k_tile = tile / ntn == 0;
+  const int n0 = (int)(tile % ntn) * BNn;
+  const int kb = (int)(tile / ntn) * BKc;
 
   // dy staging: chunk index tid + NTHR*i -> (row, col)
   int d_row[DCH], d_lds[DCH];
@@ -1052,14 +1069,22 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const elem_t*
     kyo = ky - g.pad;
     kxo = tap - ky * g.KW - g.pad;
   }
-  int r_b[XCH], r_y[XCH], r_x[XCH];
+  static_assert(!PW || BUF, "the pointwise variant addresses x with buffer offsets");
+  int r_b[PW ? 1 : XCH], r_y[PW ? 1 : XCH], r_x[PW ? 1 : XCH];
+  unsigned x_off[PW ? XCH : 1];  // PW: running byte offset of this thread's chunk in staged row i
+  if constexpr (PW) {
 #pragma unroll
-  for (int i = 0; i < XCH; ++i) {
-    const RowCoord rc = decode_row(mbeg + xr + XSTEP * i, M, g);
-    r_b[i] = rc.b;
-    r_y[i] = rc.oy;
-    r_x[i] = rc.ox;
+    for (int i = 0; i < XCH; ++i) x_off[i] = (unsigned)(((mbeg + xr + XSTEP * i) * (long)g.ldx + k) << 1);
+  } else {
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      const RowCoord rc = decode_row(mbeg + xr + XSTEP * i, M, g);
+      r_b[i] = rc.b;
+      r_y[i] = rc.oy;
+      r_x[i] = rc.ox;
+    }
   }
+  const unsigned x_step = (unsigned)((long)TN_ROWS * g.ldx * 2);
   __amdgpu_buffer_rsrc_t rs_x, rs_d;
   if constexpr (BUF) {
     rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, (short)0, (int)x_bytes, 0x00020000);
@@ -1071,7 +1096,10 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const elem_t*
   // Staging registers.  DEEP (tiles whose register budget allows it): two sets, i.e. the loads of chunk it+2 AND it+3 are in
   // flight behind chunk it's products - with one set a 64-row iteration lasted as long as a global load takes to return
   // (~4 200 cycles against 1 536 on the matrix cores)
-  constexpr bool DEEP = VKAS_TN_DEEP && TNn <= 6 && WN * WK >= (VKAS_TN_DEEP > 1 ? 4 : 8);
+  // (no room for the second set beside the im2col decode's registers, nor beside the GELU polynomial's temporaries at TNn = 6)
+  // (an 8-wave 128 x 256 tile has room for both sets beside the bias sums or the GELU polynomial - built, measured, slower than
+  // the 192-wide tile with one set: profiles/experiments/README.md)
+  constexpr bool DEEP = VKAS_TN_DEEP && PW && TNn <= 6 && !XG && NOBIAS && WN * WK >= (VKAS_TN_DEEP > 1 ? 4 : 8);
   elem8 rdA[DCH], rxA[XCH], rdB[DEEP ? DCH : 1], rxB[DEEP ? XCH : 1];
   long mcur = mbeg;
   auto load_tile = [&](elem8 (&rd)[DCH], elem8 (&rx)[XCH]) {
@@ -1091,6 +1119,12 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const elem_t*
     }
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
+      if constexpr (PW) {
+        const bool ok = k_ok && mcur + xr + XSTEP * i < mend;
+        rx[i] = __builtin_bit_cast(elem8, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? x_off[i] : OOB, 0, 0));
+        x_off[i] += x_step;
+        continue;
+      }
       const int iy = r_y[i] * g.stride + kyo, ix = r_x[i] * g.stride + kxo;
       const bool ok = k_ok && mcur + xr + XSTEP * i < mend && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
       if constexpr (BUF) {
@@ -1126,6 +1160,7 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const elem_t*
         for (int q = 0; q < 8; ++q) v[q] = (elem_t)gelu_t<elem_t>((float)v[q]);
       }
       *reinterpret_cast<elem8*>(Xs + (xr + XSTEP * i) * LDX + xc * 8) = v;
+      if constexpr (XG && DEEP) __builtin_amdgcn_sched_barrier(0);  // one chunk's polynomial temporaries at a time
     }
   };
 
@@ -1135,20 +1170,26 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const elem_t*
 #pragma unroll
     for (int j = 0; j < TK; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // bias gradient = column sums of dy: the first K block's wk == 0 waves add up the dy fragments they already hold
-  const bool do_bias = gb != nullptr && first_k_tile && wk == 0;
+  // bias gradient = column sums of dy: the first K block's wk == 0 waves add up the dy fragments they already hold, two
+  // elements per v_dot2c_f32_{bf16,f16} against (1, 1) - 4 instructions per fragment.  (Until round 4: one conversion and one
+  // add per element, ~390 vector instructions per two iterations in the loop of every wave - the branch is wave uniform, the
+  // registers are not -, which pushed the 8-wave tiles into scratch once both staging sets were really live.)
+  const bool do_bias = !NOBIAS && gb != nullptr && first_k_tile && wk == 0;
   float bsum[TNn];
 #pragma unroll
   for (int i = 0; i < TNn; ++i) bsum[i] = 0.f;
 
   const long nrows = mend - mbeg;
   const int nit = (int)((nrows + TN_ROWS - 1) / TN_ROWS);
+  // Every load_tile / store_tile below is UNCONDITIONAL (a chunk behind the last one is all out-of-range requests, which
+  // return zeros): the compiler derives its s_waitcnt vmcnt(N) from the number of loads it can prove to be outstanding, and
+  // with `if (it + 3 < nit) load_tile(...)` it had to assume none were - store_tile of the older set then waited vmcnt(0),
+  // i.e. for the set issued half an iteration earlier as well, and the second set bought nothing (round 4, ISA census).
   if (nit > 0) {
     load_tile(rdA, rxA);
     store_tile(0, rdA, rxA);
-    if (nit > 1) load_tile(rdA, rxA);  // set A now holds chunk 1
-    if constexpr (DEEP) {
-      if (nit > 2) load_tile(reinterpret_cast<elem8(&)[DCH]>(rdB), reinterpret_cast<elem8(&)[XCH]>(rxB));  // set B: chunk 2
-    }
+    load_tile(rdA, rxA);  // set A now holds chunk 1
+    if constexpr (DEEP) load_tile(reinterpret_cast<elem8(&)[DCH]>(rdB), reinterpret_cast<elem8(&)[XCH]>(rxB));  // set B: chunk 2
   }
   __syncthreads();
   // one iteration; rdS / rxS hold chunk it+1 (DEEP: chunk c >= 1 travels in set A when c is odd, in set B when even)
@@ -1158,6 +1199,9 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const elem_t*
     const elem_t* Xs = Ds + TN_ROWS * LDD;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
+      // the second half's fragments are not read ahead of the first half's products: with both halves' fragments, two staging
+      // sets and the accumulators live at once the 8-wave tiles spill, and a scratch reload waits for EVERY outstanding load
+      if (DEEP && s == 1) __builtin_amdgcn_sched_barrier(0);
       elem8 fd[TNn], fx[TK];
 #pragma unroll
       for (int i = 0; i < TNn; ++i) fd[i] = tr_frag<LDD>(Ds, s * 32, wn * TNn * 16 + i * 16, lane);
@@ -1172,22 +1216,28 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const elem_t*
       __builtin_amdgcn_s_setprio(0);
       if (do_bias) {
 #pragma unroll
-        for (int i = 0; i < TNn; ++i)
+        for (int i = 0; i < TNn; ++i) {
+          const u32x4 w = __builtin_bit_cast(u32x4, fd[i]);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) bsum[i] += (float)fd[i][q];
+          for (int q = 0; q < 4; ++q) bsum[i] = dot2_ones(w[q], bsum[i]);
+        }
       }
-      if (s == 0 && it + 1 < nit) {  // stage chunk it+1 and reissue loads into the set it leaves behind the MFMAs
+      if (s == 0) {  // stage chunk it+1 and reissue loads into the set it leaves behind the MFMAs
+        // (XG: the polynomial's temporaries only fit once the first half's fragments are dead - keep it behind those MFMAs)
+        if constexpr (XG && DEEP) __builtin_amdgcn_sched_barrier(0);
         store_tile(buf ^ 1, rdS, rxS);
-        if (it + (DEEP ? 3 : 2) < nit) load_tile(rdS, rxS);
+        load_tile(rdS, rxS);
       }
     }
     __syncthreads();
   };
   if constexpr (DEEP) {
-    for (int it = 0; it < nit; it += 2) {
+    int it = 0;
+    for (; it + 1 < nit; it += 2) {
       iteration(it, rdA, rxA);
-      if (it + 1 < nit) iteration(it + 1, reinterpret_cast<elem8(&)[DCH]>(rdB), reinterpret_cast<elem8(&)[XCH]>(rxB));
+      iteration(it + 1, reinterpret_cast<elem8(&)[DCH]>(rdB), reinterpret_cast<elem8(&)[XCH]>(rxB));
     }
+    if (it < nit) iteration(it, rdA, rxA);
   } else {
     for (int it = 0; it < nit; ++it) iteration(it, rdA, rxA);
   }
@@ -1201,7 +1251,11 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const elem_t*
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn * TNn * 16 + i * 16 + (lane >> 4) * 4 + r;
+#ifdef TN_NOATOMIC  // timing-only ablation (profiles/build_variant.sh): the reduction tail is skipped
+        if (n < Np && acc[i][j][r] == 1.2345f) atomicAdd(gw + (long)n * K + kk, acc[i][j][r]);
+#else
         if (n < Np) atomicAdd(gw + (long)n * K + kk, acc[i][j][r]);
+#endif
       }
     }
   }
@@ -1737,7 +1791,14 @@ static void launch_tn(const void* x, const vkas_conv_geom* g, const void* dy, lo
   const long x_bytes = (((long)g->B * g->Hin * g->Win - 1) * g->ldx + g->Cp) * 2;
   const long dy_bytes = ((M - 1) * lddy + Np) * 2;
   static const bool no_buf = getenv("VKAS_TN_NOBUF") != nullptr;
-  if (!no_buf && x_bytes < 0xFFFFFFF0L && dy_bytes < 0xFFFFFFF0L)
+  const bool pointwise = g->KH == 1 && g->KW == 1 && g->stride == 1 && g->pad == 0 && g->Hin == g->Hout && g->Win == g->Wout;
+  if (!no_buf && x_bytes < 0xFFFFFFF0L && dy_bytes < 0xFFFFFFF0L && pointwise && gb == nullptr && !XG && TNn == 6)
+    gemm_tn_mfma_kernel<WN, WK, TNn, TK, true, XG, true, !XG && TNn == 6><<<grid, WN * WK * 64, 0, st>>>(
+        (const elem_t*)x, *g, (const elem_t*)dy, lddy, Np, M, K, rows, gw, gb, (unsigned)x_bytes, (unsigned)dy_bytes);
+  else if (!no_buf && x_bytes < 0xFFFFFFF0L && dy_bytes < 0xFFFFFFF0L && pointwise)
+    gemm_tn_mfma_kernel<WN, WK, TNn, TK, true, XG, true><<<grid, WN * WK * 64, 0, st>>>(
+        (const elem_t*)x, *g, (const elem_t*)dy, lddy, Np, M, K, rows, gw, gb, (unsigned)x_bytes, (unsigned)dy_bytes);
+  else if (!no_buf && x_bytes < 0xFFFFFFF0L && dy_bytes < 0xFFFFFFF0L)
     gemm_tn_mfma_kernel<WN, WK, TNn, TK, true, XG><<<grid, WN * WK * 64, 0, st>>>((const elem_t*)x, *g, (const elem_t*)dy, lddy, Np,
                                                                              M, K, rows, gw, gb, (unsigned)x_bytes,
                                                                              (unsigned)dy_bytes);
