@@ -1099,6 +1099,8 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const elem_t*
   // (no room for the second set beside the im2col decode's registers, nor beside the GELU polynomial's temporaries at TNn = 6)
   // (an 8-wave 128 x 256 tile has room for both sets beside the bias sums or the GELU polynomial - built, measured, slower than
   // the 192-wide tile with one set: profiles/experiments/README.md)
+  // (four 512-register waves of 96 x 128 - 14 fragments per 48 products instead of 10 per 24 - were compiled: the 192 accumulators
+  // go to AGPRs, but staging sets + fragments exceed the 256 architectural registers and spill, with or without the second set)
   constexpr bool DEEP = VKAS_TN_DEEP && PW && TNn <= 6 && !XG && NOBIAS && WN * WK >= (VKAS_TN_DEEP > 1 ? 4 : 8);
   elem8 rdA[DCH], rxA[XCH], rdB[DEEP ? DCH : 1], rxB[DEEP ? XCH : 1];
   long mcur = mbeg;
