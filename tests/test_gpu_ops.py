@@ -176,6 +176,37 @@ torch.save({'y': y.float().cpu(), 'gx': x.grad.float().cpu(), 'gw': w.grad.cpu()
         assert rel_err(outs[0][k], outs[1][k]) < 3e-3, k
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+@pytest.mark.parametrize('variant', ['bias', 'nobias', 'gelu'])
+def test_pointwise_wgrad_8wave_tiles(variant, dtype):
+    """Weight (and bias) gradient of a pointwise layer at the sizes that take the 8-wave 192-wide tile of gemm_tn_mfma_kernel
+    (M >= 16 384 rows): the variant with bias sums (v_dot2c against ones), the one compiled without them (second staging set in
+    flight) and the one that applies GELU to the staged operand - ragged M / N / K tails - against fp64 math on the stored
+    operands."""
+    ops = ops_mod()
+    from vkit_ocr_model_adaptive_scaling_amd import _lib
+    import ctypes
+    g = torch.Generator().manual_seed(17)
+    M, N, K = 16384 + 72, 376, 264
+    x = (torch.randn((M, K), generator=g) * 1.5).to(dtype).cuda()
+    dy = torch.randn((M, N), generator=g).to(dtype).cuda()
+    gw = torch.zeros((N * K + N,), device='cuda')
+    geom = _lib.ConvGeom(1, 1, M, 1, M, K, K, 1, 1, 1, 0)
+    assert _lib.lib.vkas_conv_gemm_kernel_id(1, ctypes.byref(geom), N, N, 0) == 192
+    fn = _lib.lib.vkas_conv_gemm_wgrad_gelu if variant == 'gelu' else _lib.lib.vkas_conv_gemm_wgrad
+    gb = None if variant == 'nobias' else gw.data_ptr() + 4 * N * K
+    rc = fn(x.data_ptr(), ctypes.byref(geom), dy.data_ptr(), N, N, gw.data_ptr(), gb,
+            _lib.BF16 if dtype == torch.bfloat16 else _lib.F16, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    xr = x.double().cpu()
+    if variant == 'gelu':
+        xr = O.gelu(xr).to(dtype).double()  # the kernel rounds gelu(x) to the storage type, as the forward's GEMM-b operand was
+    ref_w = dy.double().cpu().t() @ xr
+    close(gw[:N * K].view(N, K), ref_w, dtype, 'weight gradient')
+    ref_b = torch.zeros(N, dtype=torch.float64) if variant == 'nobias' else dy.double().cpu().sum(0)
+    assert rel_err(gw[N * K:].double().cpu(), ref_b) < 1e-5 if variant != 'nobias' else float(gw[N * K:].abs().max()) == 0.0
+
+
 def test_ring_kernel_matches_register_staged_kernel_bitwise():
     """gemm_nt_ring_kernel (launches of few tiles: LDS-DMA ring) against gemm_nt_mfma_kernel<2,2,4,4> in a second process with
     VKAS_NT_RING=0: same geometry decode, K order and epilogue, so the outputs are bit-identical - pointwise shapes with M / N / K
