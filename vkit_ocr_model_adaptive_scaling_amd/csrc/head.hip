@@ -79,14 +79,18 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
   }
   __syncthreads();
   const float* hp = sp + head * 6 * pw;
-  float dg[8], db[8], dwp[OCM][8], dbp[OCM];
+  // element pairs (round 4): packed fp32 arithmetic - v_pk_fma_f32 / v_pk_mul_f32 issue at the rate of their scalar forms, and
+  // this kernel is bound by its vector instructions.  GELU' is the degree-9 polynomial of the MLP's GELU' epilogue (|error| <=
+  // 1.8e-4) instead of Phi + u phi with a v_exp_f32 (quarter rate, and not packable).
+  f32x2 dg[4], db[4], dwp[OCM][4];
+  float dbp[OCM];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) { dg[c] = 0.f; db[c] = 0.f; }
+  for (int c = 0; c < 4; ++c) { dg[c] = f32x2{0.f, 0.f}; db[c] = f32x2{0.f, 0.f}; }
 #pragma unroll
   for (int q = 0; q < OCM; ++q) {
     dbp[q] = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) dwp[q][c] = 0.f;
+    for (int c = 0; c < 4; ++c) dwp[q][c] = f32x2{0.f, 0.f};
   }
   // channel validity of this lane's 8 channels as a mask of multiplicative 0/1 (pad channels carry gamma = beta = 0 and
   // Wproj = 0, so only the LayerNorm sums need it)
@@ -132,36 +136,33 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
       load8(hp + lo, gm);
       load8(hp + pw + lo, bt);
     }
-    float g[RR][8], s1[RR], s2[RR];
+    f32x2 g[RR][4], hh[RR][4];
+    float s1[RR], s2[RR];
+    f32x2 gm2[4], bt2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      gm2[c] = f32x2{gm[2 * c], gm[2 * c + 1]};
+      bt2[c] = f32x2{bt[2 * c], bt[2 * c + 1]};
+    }
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
       const float d4[4] = {d4v[r].x, d4v[r].y, d4v[r].z, d4v[r].w};
-      s1[r] = 0.f;
-      s2[r] = 0.f;
       if (gl == 0) {
 #pragma unroll
         for (int q = 0; q < OCM; ++q) dbp[q] += d4[q];
       }
-      float act[8], gp[8], da[8];
+      f32x2 act[4], gp[4], da[4];
+      const f32x2 rs2 = pk_splat(rs[r]), nmr = pk_splat(-mu[r] * rs[r]);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
+      for (int c = 0; c < 4; ++c) {
         // (no validity masks in the sums: a pad channel has gamma = beta = Wproj = 0, so its d(act) and everything derived
         // from it is zero whatever h is; a row beyond the block has zero statistics and zero d(proj))
-        const float h = (x[r][c] - mu[r]) * rs[r];
-        const float u = fmaf(h, gm[c], bt[c]);
-        if constexpr (sizeof(T) == 2) {
-          float cdf, pdf;
-          gelu_parts_fast(u, cdf, pdf);
-          act[c] = fmaxf(u, -4.25f) * cdf;  // as gelu_t<T>
-          gp[c] = fmaf(u, pdf, cdf);
-        } else {
-          const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
-          const float pdf = 0.39894228040143268f * __expf(-0.5f * u * u);
-          act[c] = u * cdf;
-          gp[c] = fmaf(u, pdf, cdf);
-        }
-        x[r][c] = h;
-        da[c] = 0.f;
+        const f32x2 h = pk_fma(f32x2{x[r][2 * c], x[r][2 * c + 1]}, rs2, nmr);
+        const f32x2 u = pk_fma(h, gm2[c], bt2[c]);
+        act[c] = gelu2_t<T>(u);
+        gp[c] = dgelu2_t<T>(u);
+        hh[r][c] = h;
+        da[c] = f32x2{0.f, 0.f};
       }
 #pragma unroll
       for (int q = 0; q < OCM; ++q) {
@@ -169,22 +170,26 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
 #pragma unroll
         for (int c = 0; c < 8; ++c) wp[c] = 0.f;
         if (vok) load8(hp + (2 + q) * pw + lo, wp);
+        const f32x2 dq = pk_splat(d4[q]);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          da[c] = fmaf(d4[q], wp[c], da[c]);
-          dwp[q][c] = fmaf(d4[q], act[c], dwp[q][c]);
+        for (int c = 0; c < 4; ++c) {
+          da[c] = pk_fma(dq, f32x2{wp[2 * c], wp[2 * c + 1]}, da[c]);
+          dwp[q][c] = pk_fma(dq, act[c], dwp[q][c]);
         }
       }
+      f32x2 t1 = {0.f, 0.f}, t2 = {0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float gg = da[c] * gp[c];
+      for (int c = 0; c < 4; ++c) {
+        const f32x2 gg = da[c] * gp[c];
         g[r][c] = gg;
-        dg[c] = fmaf(gg, x[r][c], dg[c]);
+        dg[c] = pk_fma(gg, hh[r][c], dg[c]);
         db[c] += gg;
-        const float dxh = gg * gm[c];
-        s1[r] += dxh;
-        s2[r] = fmaf(dxh, x[r][c], s2[r]);
+        const f32x2 dxh = gg * gm2[c];
+        t1 += dxh;
+        t2 = pk_fma(dxh, hh[r][c], t2);
       }
+      s1[r] = t1.x + t1.y;
+      s2[r] = t2.x + t2.y;
     }
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
@@ -198,8 +203,13 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
       const long m = m0 + (long)r * rpi + rl;
       if (m >= mend || !vok) continue;
       float o[8];
+      const f32x2 ns1 = pk_splat(-s1[r]), ns2 = pk_splat(-s2[r]), rs2 = pk_splat(rs[r]);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) o[c] = cm[c] * rs[r] * (g[r][c] * gm[c] - s1[r] - x[r][c] * s2[r]);
+      for (int c = 0; c < 4; ++c) {
+        const f32x2 v = f32x2{cm[2 * c], cm[2 * c + 1]} * rs2 * pk_fma(hh[r][c], ns2, pk_fma(g[r][c], gm2[c], ns1));
+        o[2 * c] = v.x;
+        o[2 * c + 1] = v.y;
+      }
       store8(dz + m * lddz + n0 + gl * 8, o);
     }
   }
@@ -221,13 +231,24 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
       }
     }
   };
-  reduce_store(dg, 0);
-  reduce_store(db, pw);
+  auto flat8 = [](const f32x2 (&v)[4], float (&f)[8]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { f[2 * c] = v[c].x; f[2 * c + 1] = v[c].y; }
+  };
+  float f8[8];
+  flat8(dg, f8);
+  reduce_store(f8, 0);
+  flat8(db, f8);
+  reduce_store(f8, pw);
   const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    if (q < OCM) reduce_store(dwp[q < OCM ? q : 0], (2 + q) * pw);
-    else reduce_store(zero8, (2 + q) * pw);
+    if (q < OCM) {
+      flat8(dwp[q < OCM ? q : 0], f8);
+      reduce_store(f8, (2 + q) * pw);
+    } else {
+      reduce_store(zero8, (2 + q) * pw);
+    }
   }
   float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -284,31 +305,50 @@ __global__ __launch_bounds__(256) void head_tail_fwd_kernel(const T* __restrict_
     for (int q = 0; q < 4; ++q) load8(hp + (2 + q) * pw + gl * 8, wp[q]);
   }
   const float invC = 1.f / (float)C;
-  for (long m = (long)blockIdx.x * rpi + rl; m < M; m += (long)gridDim.x * rpi) {
+  // four rows per trip: their 16-byte pieces are requested together as raw registers before the first one is converted (round 4;
+  // one row per trip left every row's memory round trip exposed: 1.30 ms for 573 k pixels x 4 heads of config #5)
+  constexpr int RU = 4;
+  const long stride = (long)gridDim.x * rpi;
+  for (long m0 = (long)blockIdx.x * rpi + rl; m0 < M; m0 += RU * stride) {
+    Raw8<T> raw[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      raw[u].zero();
+      if (vok && m0 + u * stride < M) raw[u].load(z + (m0 + u * stride) * ldz + n0 + gl * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+    const long m = m0 + u * stride;
+    if (m >= M) break;
     float x[8];
+    raw[u].unpack(x);
+    // element pairs: packed fp32 arithmetic (v_pk_fma_f32 ...) - the kernel is bound by its vector instructions, not by HBM
+    f32x2 xp[4], s2 = {0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 8; ++c) x[c] = 0.f;
-    if (vok) load8(z + m * ldz + n0 + gl * 8, x);
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) s += x[c] * cm[c];
-    const float mean = group_sum<G>(s) * invC;
-    float q2 = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const float d = (x[c] - mean) * cm[c];
-      q2 = fmaf(d, d, q2);
+    for (int c = 0; c < 4; ++c) {
+      xp[c] = f32x2{x[2 * c], x[2 * c + 1]};
+      s2 = pk_fma(xp[c], f32x2{cm[2 * c], cm[2 * c + 1]}, s2);
     }
-    const float rstd = rsqrtf(group_sum<G>(q2) * invC + 1e-6f);
-    float pr[4] = {0.f, 0.f, 0.f, 0.f};
+    const float mean = group_sum<G>(s2.x + s2.y) * invC;
+    f32x2 q2 = {0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const float act = gelu_t<T>((x[c] - mean) * rstd * gm[c] + bt[c]) * cm[c];  // pad channels: gamma = beta = 0
-#pragma unroll
-      for (int q = 0; q < 4; ++q) pr[q] = fmaf(act, wp[q][c], pr[q]);
+    for (int c = 0; c < 4; ++c) {
+      xp[c] = (xp[c] - pk_splat(mean)) * f32x2{cm[2 * c], cm[2 * c + 1]};
+      q2 = pk_fma(xp[c], xp[c], q2);
     }
+    const float rstd = rsqrtf(group_sum<G>(q2.x + q2.y) * invC + 1e-6f);
+    f32x2 pr2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pr[q] = group_sum<G>(pr[q]);
+    for (int c = 0; c < 4; ++c) {
+      // pad channels: gamma = beta = 0 and the mask
+      const f32x2 g2 = f32x2{gm[2 * c], gm[2 * c + 1]} * pk_splat(rstd);
+      const f32x2 act = gelu2_t<T>(pk_fma(xp[c], g2, f32x2{bt[2 * c], bt[2 * c + 1]})) * f32x2{cm[2 * c], cm[2 * c + 1]};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pr2[q] = pk_fma(act, f32x2{wp[q][2 * c], wp[q][2 * c + 1]}, pr2[q]);
+    }
+    float pr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pr[q] = group_sum<G>(pr2[q].x + pr2[q].y);
     if (gl == 0 && hok) {
       const float4 bp = *reinterpret_cast<const float4*>(hp + 6 * pw);
       float* po = proj + ((long)head * M + m) * 8;
@@ -318,6 +358,7 @@ __global__ __launch_bounds__(256) void head_tail_fwd_kernel(const T* __restrict_
         stats[((long)head * M + m) * 2] = mean;
         stats[((long)head * M + m) * 2 + 1] = rstd;
       }
+    }
     }
   }
 }

@@ -43,6 +43,24 @@ __host__ __device__ constexpr int chain_ka(int KS) { return ((KS + 1) / 2) * 64;
 // per chunk: GEMM-a tile + GEMM-b tile + one 1-KB piece whose first 128 bytes hold the chunk's 32 GEMM-a biases (fp32)
 __host__ __device__ constexpr int chain_img_elems(int KS) { return 32 * chain_ka(KS) + KS * 32 * 32 + 512; }
 
+// GELU / d * GELU' of four stored values, two per packed instruction (vkas_common.h: gelu2_t / dgelu2_t - the same operations per
+// component as gelu_t / dgelu_t, so nothing changes in the results)
+template <typename T, typename V4>
+__device__ __forceinline__ V4 chain_gelu4(const V4& h) {
+  const f32x2 a = gelu2_t<T>(f32x2{(float)h[0], (float)h[1]}), b = gelu2_t<T>(f32x2{(float)h[2], (float)h[3]});
+  V4 o;
+  o[0] = (T)a.x; o[1] = (T)a.y; o[2] = (T)b.x; o[3] = (T)b.y;
+  return o;
+}
+template <typename T, typename V4>
+__device__ __forceinline__ V4 chain_dgelu4(const V4& h, const f32x4& d) {
+  const f32x2 a = f32x2{d[0], d[1]} * dgelu2_t<T>(f32x2{(float)h[0], (float)h[1]});
+  const f32x2 b = f32x2{d[2], d[3]} * dgelu2_t<T>(f32x2{(float)h[2], (float)h[3]});
+  V4 o;
+  o[0] = (T)a.x; o[1] = (T)a.y; o[2] = (T)b.x; o[3] = (T)b.y;
+  return o;
+}
+
 // ---- packed weight image -------------------------------------------------------------------------------------------
 // chunk j (hidden units 32 j .. 32 j + 31):
 //   A region: sub-tiles s = 0 .. KA/64 - 1 of [32 hidden][64 k], 16-byte chunk c of row h stored at position c ^ (h & 7);
@@ -352,10 +370,11 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
         *reinterpret_cast<v4*>(stg + stg_off(r, e0)) = h0;
         *reinterpret_cast<v4*>(stg + stg_off(r, e0 + 16)) = h1;
         // GELU of the stored (rounded) pre-activation: what backward will differentiate
+        const v4 g0 = (ABL & 4) ? h0 : chain_gelu4<T, v4>(h0), g1 = (ABL & 4) ? h1 : chain_gelu4<T, v4>(h1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          gf[i][q] = (ABL & 4) ? h0[q] : (T)gelu_t<T>((float)h0[q]);
-          gf[i][4 + q] = (ABL & 4) ? h1[q] : (T)gelu_t<T>((float)h1[q]);
+          gf[i][q] = g0[q];
+          gf[i][4 + q] = g1[q];
         }
       }
     } else {
@@ -372,10 +391,15 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
         const v4 h0 = *reinterpret_cast<const v4*>(stg + stg_off(r, e0));
         const v4 h1 = *reinterpret_cast<const v4*>(stg + stg_off(r, e0 + 16));
         v4 o0, o1;
+        if constexpr ((ABL & 4) != 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          o0[q] = (T)(d[i][0][q] * ((ABL & 4) ? (float)h0[q] : dgelu_t<T>((float)h0[q])));
-          o1[q] = (T)(d[i][1][q] * ((ABL & 4) ? (float)h1[q] : dgelu_t<T>((float)h1[q])));
+          for (int q = 0; q < 4; ++q) {
+            o0[q] = (T)(d[i][0][q] * (float)h0[q]);
+            o1[q] = (T)(d[i][1][q] * (float)h1[q]);
+          }
+        } else {
+          o0 = chain_dgelu4<T, v4>(h0, d[i][0]);
+          o1 = chain_dgelu4<T, v4>(h1, d[i][1]);
         }
         *reinterpret_cast<v4*>(stg + stg_off(r, e0)) = o0;  // in place: dh over h
         *reinterpret_cast<v4*>(stg + stg_off(r, e0 + 16)) = o1;
@@ -895,19 +919,28 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(ChainArgs p) {
             *reinterpret_cast<v4*>(stg + stg_off(r, e0 + 16)) = h1;
           }
           // GELU of the stored (rounded) pre-activation: what backward will differentiate
+          const v4 g0 = (ABL & 4) ? h0 : chain_gelu4<T, v4>(h0), g1 = (ABL & 4) ? h1 : chain_gelu4<T, v4>(h1);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            own[i][q] = (ABL & 4) ? h0[q] : (T)gelu_t<T>((float)h0[q]);
-            own[i][4 + q] = (ABL & 4) ? h1[q] : (T)gelu_t<T>((float)h1[q]);
+            own[i][q] = g0[q];
+            own[i][4 + q] = g1[q];
           }
         } else {
           h0 = hq[i][0];
           h1 = hq[i][1];
           v4 o0, o1;
+          if constexpr ((ABL & 4) != 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              o0[q] = (T)(d[i][0][q] * (float)h0[q]);
+              o1[q] = (T)(d[i][1][q] * (float)h1[q]);
+            }
+          } else {
+            o0 = chain_dgelu4<T, v4>(h0, d[i][0]);
+            o1 = chain_dgelu4<T, v4>(h1, d[i][1]);
+          }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            o0[q] = (T)(d[i][0][q] * ((ABL & 4) ? (float)h0[q] : dgelu_t<T>((float)h0[q])));
-            o1[q] = (T)(d[i][1][q] * ((ABL & 4) ? (float)h1[q] : dgelu_t<T>((float)h1[q])));
             own[i][q] = o0[q];
             own[i][4 + q] = o1[q];
           }

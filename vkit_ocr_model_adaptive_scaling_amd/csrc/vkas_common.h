@@ -1,6 +1,8 @@
 // Shared host/device helpers for libvkas (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -206,6 +208,53 @@ template <> __device__ __forceinline__ float dgelu_t<bf16_t>(float x) {
   p = fmaf(p, u, -2.6492567818e-01f);
   p = fmaf(p, u, 7.9762614621e-01f);
   return fmaf(xc, p, 0.5f);
+}
+
+// Two elements per instruction (round 4): CDNA3/4 issue v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 at the rate of their scalar forms,
+// i.e. a polynomial on a PAIR costs what it costs on one element; the constants ride in SGPRs (op_sel broadcast).  Same operations in
+// the same order per component as gelu_t / dgelu_t: bit-identical results.  fp32 storage keeps the exact (erf) forms per component.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_splat(float c) { return f32x2{c, c}; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+template <typename T> __device__ __forceinline__ f32x2 gelu2_t(f32x2 x) {
+  if constexpr (std::is_same<T, float>::value) {
+    return f32x2{gelu_f(x.x), gelu_f(x.y)};
+  } else {
+    const f32x2 xc = {__builtin_amdgcn_fmed3f(x.x, -4.25f, 4.25f), __builtin_amdgcn_fmed3f(x.y, -4.25f, 4.25f)};
+    const f32x2 u = xc * xc;
+    f32x2 p = pk_splat(5.5648210864e-11f);
+    p = pk_fma(p, u, pk_splat(-5.3277341912e-09f));
+    p = pk_fma(p, u, pk_splat(2.2554223425e-07f));
+    p = pk_fma(p, u, pk_splat(-5.6264222408e-06f));
+    p = pk_fma(p, u, pk_splat(9.3418689023e-05f));
+    p = pk_fma(p, u, pk_splat(-1.1085611169e-03f));
+    p = pk_fma(p, u, pk_splat(9.8159725707e-03f));
+    p = pk_fma(p, u, pk_splat(-6.6344495031e-02f));
+    p = pk_fma(p, u, pk_splat(3.9890234175e-01f));
+    const f32x2 cdf = pk_fma(xc, p, pk_splat(0.5f));
+    // max(x, -4.25) as a median with a huge upper bound: one instruction, no canonicalising v_max in front of it
+    const f32x2 xm = {__builtin_amdgcn_fmed3f(x.x, -4.25f, 3.0e38f), __builtin_amdgcn_fmed3f(x.y, -4.25f, 3.0e38f)};
+    return xm * cdf;
+  }
+}
+template <typename T> __device__ __forceinline__ f32x2 dgelu2_t(f32x2 x) {
+  if constexpr (std::is_same<T, float>::value) {
+    return f32x2{dgelu_f(x.x), dgelu_f(x.y)};
+  } else {
+    const f32x2 xc = {__builtin_amdgcn_fmed3f(x.x, -4.5f, 4.5f), __builtin_amdgcn_fmed3f(x.y, -4.5f, 4.5f)};
+    const f32x2 u = xc * xc;
+    f32x2 p = pk_splat(-2.2107989521e-11f);
+    p = pk_fma(p, u, pk_splat(2.5213160948e-09f));
+    p = pk_fma(p, u, pk_splat(-1.2680528206e-07f));
+    p = pk_fma(p, u, pk_splat(3.7219336900e-06f));
+    p = pk_fma(p, u, pk_splat(-7.1221943086e-05f));
+    p = pk_fma(p, u, pk_splat(9.4054174145e-04f));
+    p = pk_fma(p, u, pk_splat(-8.8158577153e-03f));
+    p = pk_fma(p, u, pk_splat(5.8609299903e-02f));
+    p = pk_fma(p, u, pk_splat(-2.6492567818e-01f));
+    p = pk_fma(p, u, pk_splat(7.9762614621e-01f));
+    return pk_fma(xc, p, pk_splat(0.5f));
+  }
 }
 
 // Sum over aligned groups of W consecutive lanes (W = 2 .. 64), result in every lane of the group.  Up to 16 lanes the
