@@ -142,6 +142,13 @@ int vkas_conv_gemm_fwd(const void* x, const vkas_conv_geom* g, const void* Bw, i
  * fp32 atomics. */
 int vkas_conv_gemm_wgrad(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
                          float* gb, int dtype, void* stream);
+/* the same without the split over M (no bias gradient): every gw tile is summed over all rows by one workgroup, in row
+ * order, and added once to the zero-filled gw, so the fp32 result does not depend on the order workgroups run in.  For
+ * the one use whose result is rounded into a 16-bit activation gradient afterwards (the input gradient of the heads the
+ * loss reads at label points, loss_function/adaptive_scaling.py:235-262 -> upernext.py:215-223): there the last-bit
+ * spread of atomically added partials flips 16-bit roundings from run to run and the backbone's backward amplifies it. */
+int vkas_conv_gemm_wgrad_ordered(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
+                                 int dtype, void* stream);
 /* the same with A(m,k) = gelu(x(m,k)): weight gradient of the second MLP Linear when the forward kept only the
  * pre-activation h (vkas_mlp_chain_fwd): backward of convnext.py:34-35 */
 int vkas_conv_gemm_wgrad_gelu(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,

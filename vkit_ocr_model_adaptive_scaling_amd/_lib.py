@@ -84,6 +84,7 @@ _SIGS = {
     'vkas_nchw_f32_to_nhwc': (c_int, [_P, _P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'vkas_conv_gemm_fwd': (c_int, [_P, POINTER(ConvGeom), _P, c_int, POINTER(Epilogue), c_int, _P]),
     'vkas_conv_gemm_wgrad': (c_int, [_P, POINTER(ConvGeom), _P, c_long, c_int, _P, _P, c_int, _P]),
+    'vkas_conv_gemm_wgrad_ordered': (c_int, [_P, POINTER(ConvGeom), _P, c_long, c_int, _P, c_int, _P]),
     'vkas_conv_gemm_wgrad_gelu': (c_int, [_P, POINTER(ConvGeom), _P, c_long, c_int, _P, _P, c_int, _P]),
     'vkas_mlp_chain_image_elems': (c_size_t, [c_int]),
     'vkas_mlp_chain_pack': (c_int, [_P, _P, _P, c_int, c_int, _P, c_int, _P]),

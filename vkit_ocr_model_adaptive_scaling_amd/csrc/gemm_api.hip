@@ -151,6 +151,11 @@ extern "C" int vkas_conv_gemm_wgrad(const void* x, const vkas_conv_geom* g, cons
   return conv_gemm_wgrad("vkas_conv_gemm_wgrad", x, g, dy, lddy, Np, gw, gb, 0, dtype, stream);
 }
 
+extern "C" int vkas_conv_gemm_wgrad_ordered(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np,
+                                            float* gw, int dtype, void* stream) {
+  return conv_gemm_wgrad("vkas_conv_gemm_wgrad_ordered", x, g, dy, lddy, Np, gw, nullptr, 2, dtype, stream);
+}
+
 extern "C" int vkas_conv_gemm_wgrad_gelu(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np,
                                          float* gw, float* gb, int dtype, void* stream) {
   return conv_gemm_wgrad("vkas_conv_gemm_wgrad_gelu", x, g, dy, lddy, Np, gw, gb, 1, dtype, stream);

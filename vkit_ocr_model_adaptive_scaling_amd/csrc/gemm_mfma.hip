@@ -1765,7 +1765,7 @@ int VKAS_MFMA_FN(vkas_gemm_nt_mfma)(const void* x, const vkas_conv_geom* g, cons
 
 template <int WN, int WK, int TNn, int TK, bool XG>
 static void launch_tn(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, long M, int K, float* gw,
-                      float* gb, hipStream_t st) {
+                      float* gb, bool one_split, hipStream_t st) {
   constexpr int BNn = WN * TNn * 16, BKc = WK * TK * 16;
   const long tiles = vkas_cdiv(Np, BNn) * vkas_cdiv(K, BKc);
   // Splits over M: pick the count that minimises a two-term cost model.
@@ -1777,7 +1777,9 @@ static void launch_tn(const void* x, const vkas_conv_geom* g, const void* dy, lo
   const long resident = 256L * (WN * WK >= 8 ? 1 : 2);
   const double t_iter = WN * WK >= 8 ? 1.2e-6 : 0.5e-6;
   const double tile_bytes = (double)BNn * BKc * 4.0;
-  const long max_splits = vkas_cdiv(M, 4 * TN_ROWS);
+  // one_split: every output tile is reduced over all M rows by one workgroup, in row order, and added once to the zeroed
+  // gw: the result does not depend on the order workgroups run in (vkas_conv_gemm_wgrad_ordered)
+  const long max_splits = one_split ? 1 : vkas_cdiv(M, 4 * TN_ROWS);
   long splits = 1;
   double best_t = 1e30;
   for (long sp = 1; sp <= max_splits && sp * tiles <= 8 * resident; ++sp) {
@@ -1837,14 +1839,15 @@ int vkas_gemm_tn_tile_choice(long M, int Np, int K) {
 #endif  // VKAS_MFMA_F16
 
 int VKAS_MFMA_FN(vkas_gemm_tn_mfma)(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
-                           float* gb, int x_gelu, hipStream_t st) {
+                           float* gb, int flags, hipStream_t st) {
   const long M = (long)g->B * g->Hout * g->Wout;
   const int K = g->KH * g->KW * g->Cp;
   if (M == 0) return VKAS_OK;
+  const bool x_gelu = (flags & 1) != 0, one_split = (flags & 2) != 0;
   // row-aligned 3x3 / stride 1 / pad 1 with wide operands: the slab kernel
   const long x_bytes = (((long)g->B * g->Hin * g->Win - 1) * g->ldx + g->Cp) * 2;
   const long dy_bytes = ((M - 1) * lddy + Np) * 2;
-  if (!x_gelu && vkas_tn_slab_eligible(g, Np, lddy)) {
+  if (!x_gelu && !one_split && vkas_tn_slab_eligible(g, Np, lddy)) {
     const bool n96 = vkas_tn_slab_n96(Np);
     const bool n112 = !n96 && vkas_tn_slab_n112(Np);
     const long tiles = vkas_cdiv(Np, n96 ? 96 : (n112 ? 112 : 128)) * 3 * vkas_cdiv(g->Cp, 128);
@@ -1875,12 +1878,12 @@ int VKAS_MFMA_FN(vkas_gemm_tn_mfma)(const void* x, const vkas_conv_geom* g, cons
   }
   const int bn = vkas_gemm_tn_tile_choice(M, Np, K);
   if (x_gelu) {
-    if (bn == 224) launch_tn<2, 4, 7, 4, true>(x, g, dy, lddy, Np, M, K, gw, gb, st);
-    else if (bn == 192) launch_tn<2, 4, 6, 4, true>(x, g, dy, lddy, Np, M, K, gw, gb, st);
-    else launch_tn<2, 2, 4, 4, true>(x, g, dy, lddy, Np, M, K, gw, gb, st);
-  } else if (bn == 224) launch_tn<2, 4, 7, 4, false>(x, g, dy, lddy, Np, M, K, gw, gb, st);
-  else if (bn == 192) launch_tn<2, 4, 6, 4, false>(x, g, dy, lddy, Np, M, K, gw, gb, st);
-  else launch_tn<2, 2, 4, 4, false>(x, g, dy, lddy, Np, M, K, gw, gb, st);
+    if (bn == 224) launch_tn<2, 4, 7, 4, true>(x, g, dy, lddy, Np, M, K, gw, gb, one_split, st);
+    else if (bn == 192) launch_tn<2, 4, 6, 4, true>(x, g, dy, lddy, Np, M, K, gw, gb, one_split, st);
+    else launch_tn<2, 2, 4, 4, true>(x, g, dy, lddy, Np, M, K, gw, gb, one_split, st);
+  } else if (bn == 224) launch_tn<2, 4, 7, 4, false>(x, g, dy, lddy, Np, M, K, gw, gb, one_split, st);
+  else if (bn == 192) launch_tn<2, 4, 6, 4, false>(x, g, dy, lddy, Np, M, K, gw, gb, one_split, st);
+  else launch_tn<2, 2, 4, 4, false>(x, g, dy, lddy, Np, M, K, gw, gb, one_split, st);
   VKAS_LAUNCH_CHECK("gemm_tn_mfma");
   return VKAS_OK;
 }

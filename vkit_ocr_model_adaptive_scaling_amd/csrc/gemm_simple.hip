@@ -181,13 +181,14 @@ int vkas_gemm_nt_simple(const void* x, const vkas_conv_geom* g, const void* Bw, 
 }
 
 int vkas_gemm_tn_simple(const void* x, const vkas_conv_geom* g, const void* dy, long lddy, int Np, float* gw,
-                        float* gb, int x_gelu, int dtype, hipStream_t st) {
+                        float* gb, int flags, int dtype, hipStream_t st) {
   const long M = (long)g->B * g->Hout * g->Wout;
   const int K = g->KH * g->KW * g->Cp;
   if (M == 0) return VKAS_OK;
+  const int x_gelu = flags & 1;  // flags: bit 0 = gelu on load, bit 1 = one split (see vkas_conv_gemm_wgrad_ordered)
   const long tiles = vkas_cdiv(Np, TS) * vkas_cdiv(K, TS);
   long splits = vkas_cdiv(2048, tiles);
-  const long max_splits = vkas_cdiv(M, 4 * TK);
+  const long max_splits = (flags & 2) ? 1 : vkas_cdiv(M, 4 * TK);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   if (splits > 65535) splits = 65535;

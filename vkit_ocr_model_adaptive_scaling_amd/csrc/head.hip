@@ -66,19 +66,23 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
   const int pw = a.pw, PS = 6 * pw + 8;
   const int C = hok ? a.c[head] : 1, np = hok ? a.np[head] : 0, n0 = hok ? a.n0[head] : 0;
   const float* hstats = stats + (long)head * M * 2;
-  const float* hdproj = hok ? a.dproj[head] : nullptr;
   const int nvec = np >> 3;
   const long mbeg = (long)blockIdx.x * rows_per_block;
   const long mend = mbeg + rows_per_block < M ? mbeg + rows_per_block : M;
   const bool vok = hok && gl < nvec;
   // gamma | beta | Wproj[4] of every head live in LDS (each lane re-reads its 8-channel slice per row)
-  __shared__ __attribute__((aligned(16))) float sp[NH * 6 * G * 8];
-  for (int i = threadIdx.x; i < NH * 6 * pw; i += 256) {
-    const int h = i / (6 * pw), r = i - h * 6 * pw;
-    sp[i] = h < a.n_heads ? params[(long)h * PS + r] : 0.f;
+  // Each of a head's six vectors takes G * 8 floats, zero beyond pw: every lane of a group reads its 8-channel slice
+  // UNCONDITIONALLY (lanes past the head's width get zeros).  Round 4: with these 16-byte LDS reads under a partial EXEC mask
+  // (lanes >= np / 8 off) the last active 8-lane beat of the upper half-wave sporadically delivered stale registers when a
+  // second process kept the CU's LDS busy (profiles/repro_step_determinism5.py) - full-wave reads do not.
+  constexpr int GW = G * 8;
+  __shared__ __attribute__((aligned(16))) float sp[NH * 6 * GW];
+  for (int i = threadIdx.x; i < NH * 6 * GW; i += 256) {
+    const int h = i / (6 * GW), r = i - h * 6 * GW, k = r / GW, j = r - k * GW;
+    sp[i] = (h < a.n_heads && j < pw) ? params[(long)h * PS + k * pw + j] : 0.f;
   }
   __syncthreads();
-  const float* hp = sp + head * 6 * pw;
+  const float* hp = sp + head * 6 * GW;
   // element pairs (round 4): packed fp32 arithmetic - v_pk_fma_f32 / v_pk_mul_f32 issue at the rate of their scalar forms, and
   // this kernel is bound by its vector instructions.  GELU' is the degree-9 polynomial of the MLP's GELU' epilogue (|error| <=
   // 1.8e-4) instead of Phi + u phi with a v_exp_f32 (quarter rate, and not packable).
@@ -103,16 +107,21 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
   Raw8<T> xr[RR];  // as loaded: converted when the pair is processed, not when it is requested
   float mean[RR], rstd[RR];
   float4 dp[RR];
+  // every lane loads UNCONDITIONALLY from an address that is always valid (its row clamped into the block, a lane beyond the
+  // head's width reads the head's first slice) and what it must not use is zeroed afterwards: no load under a partial EXEC mask
+  const float* hdproj_c = a.dproj[hok ? head : 0];
+  const float* hstats_c = hok ? hstats : stats;
+  const T* zcol = z + n0 + (vok ? gl : 0) * 8;
   auto fetch = [&](long m0) {
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
       const long m = m0 + (long)r * rpi + rl;
-      const bool ok = hok && m < mend;
-      mean[r] = ok ? hstats[2 * m] : 0.f;
-      rstd[r] = ok ? hstats[2 * m + 1] : 0.f;
-      dp[r] = ok ? *reinterpret_cast<const float4*>(hdproj + m * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
-      xr[r].zero();
-      if (ok && vok) xr[r].load(z + m * ldz + n0 + gl * 8);
+      const long mc = m < mend ? m : mbeg;
+      const float2 st2 = *reinterpret_cast<const float2*>(hstats_c + 2 * mc);
+      mean[r] = st2.x;
+      rstd[r] = st2.y;
+      dp[r] = *reinterpret_cast<const float4*>(hdproj_c + mc * 8);
+      xr[r].load(zcol + mc * ldz);
     }
   };
   fetch(mbeg);
@@ -121,9 +130,11 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
     float4 d4v[RR];
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
-      mu[r] = mean[r];
-      rs[r] = rstd[r];
-      d4v[r] = dp[r];
+      const bool ok = hok && m0 + (long)r * rpi + rl < mend;  // the masks of the unconditional loads, applied on use
+      mu[r] = ok ? mean[r] : 0.f;
+      rs[r] = ok ? rstd[r] : 0.f;
+      d4v[r] = ok ? dp[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+      xr[r].keep_if(ok && vok);
       xr[r].unpack(x[r]);
     }
     if (m0 + (long)RR * rpi < mend) fetch(m0 + (long)RR * rpi);  // next pair: in flight behind this pair's arithmetic
@@ -132,10 +143,8 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
     for (int c = 0; c < 8; ++c) { gm[c] = 0.f; bt[c] = 0.f; }
     int lo = gl * 8;
     asm volatile("" : "+v"(lo));  // opaque per iteration: keeps the parameter loads in the loop (LICM would pin their VGPRs)
-    if (vok) {
-      load8(hp + lo, gm);
-      load8(hp + pw + lo, bt);
-    }
+    load8(hp + lo, gm);
+    load8(hp + GW + lo, bt);
     f32x2 g[RR][4], hh[RR][4];
     float s1[RR], s2[RR];
     f32x2 gm2[4], bt2[4];
@@ -167,9 +176,7 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
 #pragma unroll
       for (int q = 0; q < OCM; ++q) {
         float wp[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) wp[c] = 0.f;
-        if (vok) load8(hp + (2 + q) * pw + lo, wp);
+        load8(hp + (2 + q) * GW + lo, wp);
         const f32x2 dq = pk_splat(d4[q]);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {

@@ -107,18 +107,21 @@ template <> struct Raw8<float> {
   float4 a, b;
   __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
   __device__ __forceinline__ void zero() { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+  __device__ __forceinline__ void keep_if(bool k) { if (!k) zero(); }
   __device__ __forceinline__ void unpack(float* v) const { v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; }
 };
 template <> struct Raw8<bf16_t> {
   bf16x8 a;
   __device__ __forceinline__ void load(const bf16_t* p) { a = *reinterpret_cast<const bf16x8*>(p); }
   __device__ __forceinline__ void zero() { for (int i = 0; i < 8; ++i) a[i] = (bf16_t)0.f; }
+  __device__ __forceinline__ void keep_if(bool k) { if (!k) zero(); }
   __device__ __forceinline__ void unpack(float* v) const { for (int i = 0; i < 8; ++i) v[i] = (float)a[i]; }
 };
 template <> struct Raw8<f16_t> {
   f16x8 a;
   __device__ __forceinline__ void load(const f16_t* p) { a = *reinterpret_cast<const f16x8*>(p); }
   __device__ __forceinline__ void zero() { for (int i = 0; i < 8; ++i) a[i] = (f16_t)0.f; }
+  __device__ __forceinline__ void keep_if(bool k) { if (!k) zero(); }
   __device__ __forceinline__ void unpack(float* v) const { for (int i = 0; i < 8; ++i) v[i] = (float)a[i]; }
 };
 

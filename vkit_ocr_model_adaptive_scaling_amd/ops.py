@@ -462,11 +462,14 @@ def deliver_small_grads(pairs):
 
 def conv_wgrad(x: torch.Tensor, geom: ConvGeom, dy: torch.Tensor, Np: int, nk=None, with_bias: bool = False,
                x_gelu: bool = False, gw_into: Optional[torch.Tensor] = None, gb_into: Optional[torch.Tensor] = None,
-               step_scratch: bool = False):
+               step_scratch: bool = False, ordered: bool = False):
     """Weight gradient in the packed (Np, K) layout; with_bias also returns the fused bias gradient (Np,): the two
     live in one zero-filled buffer so a single memset covers both.  x_gelu: the input operand is gelu(x).
     gw_into / gb_into: existing fp32 buffers to ACCUMULATE into (the kernels add with atomics) instead of fresh zeros.
-    step_scratch: the caller consumes the result before the step ends (zeros_f32)."""
+    step_scratch: the caller consumes the result before the step ends (zeros_f32).
+    ordered: no split over the reduced rows (vkas_conv_gemm_wgrad_ordered) - for a result that is rounded to a 16-bit
+    tensor further down, where the last-bit spread of atomically added partial sums would flip roundings from run to run."""
+    assert not (ordered and (with_bias or x_gelu or gw_into is not None))
     K = geom.KH * geom.KW * geom.Cp
     n_new = (0 if gw_into is not None else Np * K) + (Np if with_bias and gb_into is None else 0)
     buf = zeros_f32(n_new, x.device, step_scratch) if n_new else None
@@ -477,6 +480,10 @@ def conv_wgrad(x: torch.Tensor, geom: ConvGeom, dy: torch.Tensor, Np: int, nk=No
     M = geom.B * geom.Hout * geom.Wout
 
     def run():
+        if ordered:
+            check(lib.vkas_conv_gemm_wgrad_ordered(_p(x), ctypes.byref(geom), _p(dy), act_ld(dy), Np, _p(gw), _dt(x), _stream()),
+                  'conv_gemm_wgrad_ordered')
+            return gw
         fn = lib.vkas_conv_gemm_wgrad_gelu if x_gelu else lib.vkas_conv_gemm_wgrad
         check(fn(_p(x), ctypes.byref(geom), _p(dy), act_ld(dy), Np, _p(gw), _p(gb), _dt(x), _stream()), 'conv_gemm_wgrad')
         return (gw, gb) if with_bias else gw
@@ -1073,7 +1080,7 @@ class HeadsFused(Function):
                 Wf = pack_head_weights(ws, nps, Cp, 0, x.dtype)[offs[s0] * K:offs[s1] * K].view(1, 1, Ns, K)
                 dzt = dzs.view(Mp, Ns).t().contiguous().view(1, 1, Ns, Mp)
                 g3 = _geom(1, 1, Ns, 1, Ns, K, K, 1, 1, 1, 0)
-                D = conv_wgrad(Wf, g3, dzt, Mp, nk=(B * P, C * 9), step_scratch=True)
+                D = conv_wgrad(Wf, g3, dzt, Mp, nk=(B * P, C * 9), step_scratch=True, ordered=True)
                 check(lib.vkas_points_scatter3x3(_p(D), _p(pix), _p(pmap), Mp, B, H, W, Cp, _p(dx), act_ld(dx), _dt(x),
                                                  _stream()), 'points_scatter3x3')
         gws, gbs = [], []
@@ -1243,7 +1250,7 @@ class HeadsAtPoints(Function):
             Wf = pack_head_weights(ws, nps, Cp, 0, dtype).view(1, 1, Ns, K)
             dzt = dzs.view(Mp, Ns).t().contiguous().view(1, 1, Ns, Mp)
             g3 = _geom(1, 1, Ns, 1, Ns, K, K, 1, 1, 1, 0)
-            D = conv_wgrad(Wf, g3, dzt, Mp, nk=(B * P, C * 9), step_scratch=True)
+            D = conv_wgrad(Wf, g3, dzt, Mp, nk=(B * P, C * 9), step_scratch=True, ordered=True)
             dx = torch.zeros((B, H, W, Cp), dtype=dtype, device=dev)
             check(lib.vkas_points_scatter3x3(_p(D), _p(pix), _p(pmap), Mp, B, H, W, Cp, _p(dx), Cp, _dtc(dtype), _stream()),
                   'points_scatter3x3')
