@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const T* __restrict_
   // Each of a head's six vectors takes G * 8 floats, zero beyond pw: every lane of a group reads its 8-channel slice
   // UNCONDITIONALLY (lanes past the head's width get zeros).  Round 4: with these 16-byte LDS reads under a partial EXEC mask
   // (lanes >= np / 8 off) the last active 8-lane beat of the upper half-wave sporadically delivered stale registers when a
-  // second process kept the CU's LDS busy (profiles/repro_step_determinism5.py) - full-wave reads do not.
+  // second process kept the CU's LDS busy (profiles/repro/repro_step_determinism5.py) - full-wave reads do not.
   constexpr int GW = G * 8;
   __shared__ __attribute__((aligned(16))) float sp[NH * 6 * GW];
   for (int i = threadIdx.x; i < NH * 6 * GW; i += 256) {
