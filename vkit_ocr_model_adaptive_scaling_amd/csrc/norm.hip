@@ -71,12 +71,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const long m = mb + (long)r * rpi;
+    const long mc = m < M ? m : M - 1;
     s[r] = 0.f;
+    // unconditional loads from clamped addresses (no load under a partial EXEC mask, cf. head.hip): what a lane beyond the
+    // row count or the width reads is masked out of the sums below and never stored
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int vi = gl + i * G;
-      raw[r][i].zero();
-      if (m < M && vi < nvec) raw[r][i].load(x + m * ldx + vi * 8);
+      raw[r][i].load(x + mc * ldx + (vi < nvec ? vi : 0) * 8);
     }
   }
 #pragma unroll
@@ -115,12 +117,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int vi = gl + i * G;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { gv[i][c] = 0.f; bv[i][c] = 0.f; }
-    if (vi < nvec) {
-      load8(gamma + vi * 8, gv[i]);
-      load8(beta + vi * 8, bv[i]);
-    }
+    load8(gamma + (vi < nvec ? vi : 0) * 8, gv[i]);
+    load8(beta + (vi < nvec ? vi : 0) * 8, bv[i]);
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -168,13 +166,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     for (int c = 0; c < 8; ++c) {
       dg[i][c] = 0.f;
       db[i][c] = 0.f;
-      gm[i][c] = 0.f;
-      bt[i][c] = 0.f;
     }
-    if (vi < nvec) {  // zero padded to Cp by the caller
-      load8(gamma + vi * 8, gm[i]);
-      load8(beta + vi * 8, bt[i]);
-    }
+    // zero padded to Cp by the caller; a lane beyond the width reads the first slice (its products are masked by cok below)
+    load8(gamma + (vi < nvec ? vi : 0) * 8, gm[i]);
+    load8(beta + (vi < nvec ? vi : 0) * 8, bt[i]);
   }
   // LN_BWD_PREFETCH: the rows of the NEXT iteration are requested (as raw 16-byte pieces) before the current ones are
   // processed, so a lane keeps twice the bytes in flight
@@ -184,18 +179,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const long m = m0 + (long)r * rpi + rl;
-      const bool ok = m < mend;
-      nmean[r] = ok ? stats[2 * m] : 0.f;
-      nrstd[r] = ok ? stats[2 * m + 1] : 0.f;
+      const long mc = m < mend ? m : mbeg;  // unconditional loads from clamped addresses; the cok masks below drop the rest
+      const float2 st2 = *reinterpret_cast<const float2*>(stats + 2 * mc);
+      nmean[r] = st2.x;
+      nrstd[r] = st2.y;
 #pragma unroll
       for (int i = 0; i < MAXV; ++i) {
-        const int vi = gl + i * G;
-        nx[r][i].zero();
-        nd[r][i].zero();
-        if (ok && vi < nvec) {
-          nx[r][i].load(x + m * ldx + vi * 8);
-          nd[r][i].load(dy + m * lddy + vi * 8);
-        }
+        const int vic = gl + i * G < nvec ? gl + i * G : 0;
+        nx[r][i].load(x + mc * ldx + vic * 8);
+        nd[r][i].load(dy + mc * lddy + vic * 8);
       }
     }
   };
