@@ -14,6 +14,7 @@ is RCCL over xGMI on its own stream, ordered after the compute stream at launch 
 clip + AdamW kernels.  Gradients are averaged by pre-scaling the losses with 1/world_size.  Works with ``gloo`` on CPU
 tensors as well (tests)."""
 import os
+import warnings
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -142,6 +143,12 @@ class TwoPassStep:
         # reads nothing else of them); same losses and gradients, see ops.HeadsAtPoints
         self.label_point_forward = label_point_forward
         self._one: Optional[torch.Tensor] = None
+        if getattr(model, 'compute_dtype', None) == torch.float16:
+            # INTEGRATION.md "fp16 training": block_scale = 1e-6 (convnext.py:38) times an fp16 activation gradient underflows,
+            # the residual branches then receive no gradient at all - measured, with and without a loss scale
+            warnings.warn('TwoPassStep on a float16 model: gradients of the ConvNeXt residual branches underflow in fp16 '
+                          'storage from the reference initialisation (block_scale = 1e-6); train in bfloat16 (the default) '
+                          'and use float16 for inference only', RuntimeWarning, stacklevel=2)
 
     def _rough_loss(self, outs, b, scale):
         mask, height = outs
