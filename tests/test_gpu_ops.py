@@ -207,6 +207,35 @@ def test_pointwise_wgrad_8wave_tiles(variant, dtype):
     assert rel_err(gw[N * K:].double().cpu(), ref_b) < 1e-5 if variant != 'nobias' else float(gw[N * K:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32], ids=['bf16', 'f32'])
+def test_wgrad_ordered_is_one_split_and_reproducible(dtype):
+    """vkas_conv_gemm_wgrad_ordered (the label-point heads' input-gradient terms, HeadsFused.backward): the shape of that call
+    - few reduced rows, many output tiles - against fp64 math and against the split-M entry point, and bit-identical over
+    repeated launches (every output tile is summed by one workgroup in row order and added once to the zeroed buffer)."""
+    ops_mod()
+    from vkit_ocr_model_adaptive_scaling_amd import _lib
+    import ctypes
+    g = torch.Generator().manual_seed(23)
+    M, N, K = 584, 320, 1736  # reduced rows (the heads' z columns), output rows (label points), 9 * Cp columns
+    x = torch.randn((M, K), generator=g).to(dtype).cuda()
+    dy = torch.randn((M, N), generator=g).to(dtype).cuda()
+    geom = _lib.ConvGeom(1, 1, M, 1, M, K, K, 1, 1, 1, 0)
+    code = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for _ in range(6):
+        gw = torch.zeros((N * K,), device='cuda')
+        assert _lib.lib.vkas_conv_gemm_wgrad_ordered(x.data_ptr(), ctypes.byref(geom), dy.data_ptr(), N, N, gw.data_ptr(), code, st) == 0
+        outs.append(gw)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:]), 'ordered weight gradient differs between launches'
+    ref = dy.double().cpu().t() @ x.double().cpu()
+    assert rel_err(outs[0].view(N, K).double().cpu(), ref) < 1e-5
+    gs = torch.zeros((N * K,), device='cuda')
+    assert _lib.lib.vkas_conv_gemm_wgrad(x.data_ptr(), ctypes.byref(geom), dy.data_ptr(), N, N, gs.data_ptr(), None, code, st) == 0
+    assert rel_err(gs.double().cpu(), outs[0].double().cpu()) < 1e-6
+
+
 def test_ring_kernel_matches_register_staged_kernel_bitwise():
     """gemm_nt_ring_kernel (launches of few tiles: LDS-DMA ring) against gemm_nt_mfma_kernel<2,2,4,4> in a second process with
     VKAS_NT_RING=0: same geometry decode, K order and epilogue, so the outputs are bit-identical - pointwise shapes with M / N / K

@@ -318,10 +318,13 @@ __global__ __launch_bounds__(256) void head_tail_fwd_kernel(const T* __restrict_
   const long stride = (long)gridDim.x * rpi;
   for (long m0 = (long)blockIdx.x * rpi + rl; m0 < M; m0 += RU * stride) {
     Raw8<T> raw[RU];
+    // unconditional loads from clamped addresses, as in the backward kernel above: a lane beyond the head's width reads the
+    // head's first slice (its channel mask cm is zero), a row beyond M is never used
+    const T* zcol = z + n0 + (vok ? gl : 0) * 8;
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
-      raw[u].zero();
-      if (vok && m0 + u * stride < M) raw[u].load(z + (m0 + u * stride) * ldz + n0 + gl * 8);
+      const long mu = m0 + u * stride;
+      raw[u].load(zcol + (mu < M ? mu : M - 1) * ldz);
     }
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
