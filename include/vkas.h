@@ -169,6 +169,15 @@ int vkas_mlp_chain_pack(const float* w1, const float* w2, const float* b1, int C
 int vkas_mlp_chain_fwd(const void* yn, long ldyn, const void* img, const float* b2, const void* x, long ldx,
                        const float* colscale, const float* rowscale, int rows_per_image, void* h, long ldh, void* z,
                        long ldz, void* out, long ldo, long M, int C, int dtype, void* stream);
+/* the same with the LayerNorm in front of the MLP (convnext.py:32, helper.py:96-101; eps 1e-6) applied to the rows on their
+ * way into the first matrix product: y = the depthwise output (M, C), ln_gamma / ln_beta (C) fp32.  Training: the
+ * normalised rows yn (operand of the W1 weight gradient) and stats (M, 2) fp32 = mean | rstd per row (what
+ * vkas_layernorm_fwd writes, consumed by vkas_layernorm_bwd) are stored; inference: yn = stats = h = z = NULL and the
+ * normalised rows never reach memory.  Replaces vkas_layernorm_fwd + vkas_mlp_chain_fwd of a ConvNeXt layer. */
+int vkas_mlp_chain_ln_fwd(const void* y, long ldy, const float* ln_gamma, const float* ln_beta, void* yn, long ldyn,
+                          float* stats, const void* img, const float* b2, const void* x, long ldx, const float* colscale,
+                          const float* rowscale, int rows_per_image, void* h, long ldh, void* z, long ldz, void* out,
+                          long ldo, long M, int C, int dtype, void* stream);
 /* dh = (dz W2) * gelu'(h) (stored, operand of the W1 weight gradient); dyn = dh W1.  img_t = the mode-1 image. */
 int vkas_mlp_chain_bwd(const void* dz, long lddz, const void* img_t, const void* h, long ldh, void* dh, long lddh,
                        void* dyn, long lddyn, long M, int C, int dtype, void* stream);

@@ -366,6 +366,46 @@ def test_mlp_chain_matches_two_gemm_path(C):
     assert float(res[True][0][1].float().sub(x[1].float()).abs().max()) == 0.0, 'dropped sample must pass through'
 
 
+@pytest.mark.parametrize('C', [24, 96, 192, 384])
+def test_mlp_chain_fused_layernorm(C):
+    """LayerNorm inside the fused MLP kernel (vkas_mlp_chain_ln_fwd) against LayerNorm as its own launch in front of it
+    (vkas_layernorm_fwd + vkas_mlp_chain_fwd): the two sum a row's channels in a different order, so a normalised value may
+    differ by one 16-bit rounding - outputs, every gradient (the saved yn / stats feed the W1 weight gradient and
+    the LayerNorm backward), ragged M, and the no-grad call (nothing stored) bit-equal to the training call's output."""
+    ops = ops_mod()
+    torch.manual_seed(100 + C)
+    B, H, W = 3, 37, 29
+    x = (torch.randn(B, H, W, C, device='cuda') * 1.5 + 0.3).to(torch.bfloat16)
+    base = [torch.randn(C, 1, 7, 7) * 0.15, torch.randn(C) * 0.1, 1 + torch.randn(C) * 0.1, torch.randn(C) * 0.1,
+            (torch.randn(4 * C, C) / math.sqrt(C)).to(torch.bfloat16).float(), torch.randn(4 * C) * 0.1,
+            (torch.randn(C, 4 * C) * 0.5 / math.sqrt(C)).to(torch.bfloat16).float(), torch.randn(C) * 0.1,
+            1 + torch.randn(C, 1, 1) * 0.2]
+    names = ['dw_w', 'dw_b', 'ln_g', 'ln_b', 'w1', 'b1', 'w2', 'b2', 'scale']
+    mask = torch.tensor([1.25, 0.0, 1.0], device='cuda')
+    cot = torch.randn(B, H, W, C, device='cuda').to(torch.bfloat16)
+    res = {}
+    min_rows, no_ln = ops._CHAIN_PAIR_MIN_ROWS, ops._NO_CHAIN_LN
+    try:
+        ops._CHAIN_PAIR_MIN_ROWS = 0
+        for fused in (True, False):
+            ops._NO_CHAIN_LN = not fused
+            ps = [t.clone().cuda().requires_grad_(True) for t in base]
+            xa = x.clone().requires_grad_(True)
+            assert ops.mlp_chain_eligible(xa, C)
+            y = ops.ConvNextLayer.apply(xa, *ps, mask)
+            y.backward(cot)
+            res[fused] = [y.detach()] + [xa.grad] + [p.grad for p in ps]
+        ops._NO_CHAIN_LN = False
+        with torch.no_grad():
+            y_inf = ops.ConvNextLayer.apply(x, *[t.cuda() for t in base], mask, False)
+    finally:
+        ops._CHAIN_PAIR_MIN_ROWS = min_rows
+        ops._NO_CHAIN_LN = no_ln
+    for name, a, b in zip(['out', 'dx'] + names, res[True], res[False]):
+        assert rel_err(a, b) < (3e-3 if name == 'out' else 8e-3), (name, rel_err(a, b))
+    assert torch.equal(y_inf, res[True][0]), 'no-grad call must give the training call\'s output'
+
+
 # ------------------------------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16', 'f16'])
 @pytest.mark.parametrize('act', [False, True], ids=['ln', 'ln_gelu'])

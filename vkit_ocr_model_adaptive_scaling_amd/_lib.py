@@ -90,6 +90,8 @@ _SIGS = {
     'vkas_mlp_chain_pack': (c_int, [_P, _P, _P, c_int, c_int, _P, c_int, _P]),
     'vkas_mlp_chain_fwd': (c_int, [_P, c_long, _P, _P, _P, c_long, _P, _P, c_int, _P, c_long, _P, c_long, _P, c_long,
                                    c_long, c_int, c_int, _P]),
+    'vkas_mlp_chain_ln_fwd': (c_int, [_P, c_long, _P, _P, _P, c_long, _P, _P, _P, _P, c_long, _P, _P, c_int, _P, c_long, _P,
+                                      c_long, _P, c_long, c_long, c_int, c_int, _P]),
     'vkas_mlp_chain_bwd': (c_int, [_P, c_long, _P, _P, c_long, _P, c_long, _P, c_long, c_long, c_int, c_int, _P]),
     'vkas_conv_gemm_tile': (c_int, [c_int, c_long, c_int, c_int]),
     'vkas_conv_gemm_kernel_id': (c_int, [c_int, POINTER(ConvGeom), c_int, c_long, c_int]),

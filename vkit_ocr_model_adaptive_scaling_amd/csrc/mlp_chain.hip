@@ -133,6 +133,14 @@ struct ChainArgs {
   long ldo;
   long M;
   int C, HID;
+  // fwd, optional: `a` holds the depthwise output and LayerNorm (helper.py:96-101 as used in convnext.py:32) is applied to
+  // the rows on their way into the B fragments; ln_out / ln_stats (normalised rows, mean | rstd per row: what the standalone
+  // kernel of norm.hip writes for backward) are written when given
+  const float* ln_gamma;
+  const float* ln_beta;
+  void* ln_out;
+  long ldln;
+  float* ln_stats;
 };
 
 template <typename T> struct Frag;
@@ -144,6 +152,70 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 }
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// LayerNorm of the resident input rows (fused forward, round 4): a row's C channels sit in the KS fragments of the four
+// lanes fr, fr + 16, fr + 32, fr + 48 (k = ks*32 + g*8 .. +7), so the statistics are per-lane sums + two cross-lane steps;
+// two-pass in fp32 (mean, then centred variance, eps = 1e-6) and the same expression per element as layernorm_fwd_kernel
+// (norm.hip), rounded to the storage type once.  mrow(i) = global row of this lane's row in group i.
+template <typename T, int TM, int KS, typename V8, typename RowFn>
+__device__ __forceinline__ void chain_layernorm_rows(V8 (&xf)[TM][KS], const ChainArgs& p, RowFn mrow, int g) {
+  const int C = p.C;
+  float mean[TM], rstd[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += (float)xf[i][ks][e];  // channels beyond C were loaded as zeros
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    mean[i] = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks * 32 + g * 8 < C) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = (float)xf[i][ks][e] - mean[i];
+          q += d * d;
+        }
+      }
+    }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    rstd[i] = rsqrtf(q / (float)C + 1e-6f);
+  }
+  T* Y = reinterpret_cast<T*>(p.ln_out);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int k = ks * 32 + g * 8;
+    const bool k_ok = k < C;
+    float gv[8], bv[8];
+    load8(p.ln_gamma + (k_ok ? k : 0), gv);
+    load8(p.ln_beta + (k_ok ? k : 0), bv);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const long m = mrow(i);
+      const bool ok = k_ok && m < p.M;
+      V8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = ok ? (T)(((float)xf[i][ks][e] - mean[i]) * rstd[i] * gv[e] + bv[e]) : (T)0.f;
+      xf[i][ks] = o;
+      if (Y && ok) *reinterpret_cast<V8*>(Y + m * p.ldln + k) = o;
+    }
+  }
+  if (p.ln_stats && g == 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const long m = mrow(i);
+      if (m < p.M) {
+        p.ln_stats[2 * m] = mean[i];
+        p.ln_stats[2 * m + 1] = rstd[i];
+      }
+    }
+  }
 }
 
 template <typename T, int KS, int TM, int MODE, int MINB>
@@ -276,6 +348,9 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
       if (m < p.M && k < C) v = *reinterpret_cast<const v8*>(A + m * p.lda + k);
       xf[i][ks] = v;
     }
+  }
+  if constexpr (MODE == MODE_FWD) {
+    if (p.ln_gamma) chain_layernorm_rows<T, TM, KS>(xf, p, [&](int i) { return row0 + i * 16 + fr; }, g);
   }
   f32x4 acc[TM][NT2];
 #pragma unroll
@@ -742,6 +817,9 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(ChainArgs p) {
       }
     }
   }
+  if constexpr (MODE == MODE_FWD) {
+    if (p.ln_gamma) chain_layernorm_rows<T, TM, KS>(xf, p, [&](int i) { return row0 + (t * TM + i) * 16 + fr; }, g);
+  }
   f32x4 acc[RG][KS];
 #pragma unroll
   for (int i = 0; i < RG; ++i)
@@ -1104,9 +1182,10 @@ static int chain_check_act(const char* who, const void* p, long ld, int width) {
   return VKAS_OK;
 }
 
-extern "C" int vkas_mlp_chain_fwd(const void* yn, long ldyn, const void* img, const float* b2, const void* x, long ldx, const float* colscale, const float* rowscale, int rows_per_image, void* h, long ldh,
-                                  void* z, long ldz, void* out, long ldo, long M, int C, int dtype, void* stream) {
-  const char* who = "vkas_mlp_chain_fwd";
+static int chain_fwd_impl(const char* who, const void* yn, long ldyn, const float* ln_gamma, const float* ln_beta, void* ln_out, long ldln,
+                          float* ln_stats, const void* img, const float* b2, const void* x, long ldx, const float* colscale,
+                          const float* rowscale, int rows_per_image, void* h, long ldh, void* z, long ldz, void* out, long ldo,
+                          long M, int C, int dtype, void* stream) {
   VKAS_CHECK(dtype == VKAS_BF16 || dtype == VKAS_F16, "%s: 16-bit storage types only", who);
   VKAS_CHECK(chain_ks(C) > 0, "%s: C=%d is not covered (multiple of 8, <= 512)", who, C);
   VKAS_CHECK(img && b2 && colscale && vkas_aligned16(img) && vkas_aligned16(b2) && vkas_aligned16(colscale),
@@ -1123,11 +1202,34 @@ extern "C" int vkas_mlp_chain_fwd(const void* yn, long ldyn, const void* img, co
   a.a = yn; a.lda = ldyn; a.img = img; a.mid_out = h; a.ldm = ldh; a.bias_b = b2; a.res = x; a.ldres = ldx;
   a.colscale = colscale; a.rowscale = rowscale; a.rows_per_image = rows_per_image; a.z = z; a.ldz = ldz; a.out = out; a.ldo = ldo;
   a.M = M; a.C = C; a.HID = 4 * C;
+  a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_out = ln_out; a.ldln = ldln; a.ln_stats = ln_stats;
   rc = dtype == VKAS_BF16 ? launch_chain<bf16_t, MODE_FWD>(a, vkas_stream(stream))
                           : launch_chain<f16_t, MODE_FWD>(a, vkas_stream(stream));
   if (rc) return rc;
   VKAS_LAUNCH_CHECK("mlp_chain_fwd");
   return VKAS_OK;
+}
+
+extern "C" int vkas_mlp_chain_fwd(const void* yn, long ldyn, const void* img, const float* b2, const void* x, long ldx, const float* colscale, const float* rowscale, int rows_per_image, void* h, long ldh,
+                                  void* z, long ldz, void* out, long ldo, long M, int C, int dtype, void* stream) {
+  return chain_fwd_impl("vkas_mlp_chain_fwd", yn, ldyn, nullptr, nullptr, nullptr, 0, nullptr, img, b2, x, ldx, colscale, rowscale,
+                        rows_per_image, h, ldh, z, ldz, out, ldo, M, C, dtype, stream);
+}
+
+extern "C" int vkas_mlp_chain_ln_fwd(const void* y, long ldy, const float* ln_gamma, const float* ln_beta, void* yn, long ldyn,
+                                     float* stats, const void* img, const float* b2, const void* x, long ldx,
+                                     const float* colscale, const float* rowscale, int rows_per_image, void* h, long ldh, void* z,
+                                     long ldz, void* out, long ldo, long M, int C, int dtype, void* stream) {
+  const char* who = "vkas_mlp_chain_ln_fwd";
+  VKAS_CHECK(ln_gamma && ln_beta && vkas_aligned16(ln_gamma) && vkas_aligned16(ln_beta), "%s: null / misaligned LayerNorm parameter", who);
+  // the backward operands travel together: h, z, yn and stats all given (training) or all omitted (inference)
+  VKAS_CHECK((yn == nullptr) == (h == nullptr) && (stats == nullptr) == (h == nullptr),
+             "%s: yn and stats must be given (training) or omitted (inference) together with h and z", who);
+  if (yn) {
+    VKAS_CHECK(vkas_aligned16(yn) && ldyn >= C && ldyn % 8 == 0, "%s: bad activation operand yn (ld=%ld, width=%d)", who, ldyn, C);
+  }
+  return chain_fwd_impl(who, y, ldy, ln_gamma, ln_beta, yn, ldyn, stats, img, b2, x, ldx, colscale, rowscale, rows_per_image, h, ldh,
+                        z, ldz, out, ldo, M, C, dtype, stream);
 }
 
 extern "C" int vkas_mlp_chain_bwd(const void* dz, long lddz, const void* img_t, const void* h, long ldh, void* dh, long lddh,

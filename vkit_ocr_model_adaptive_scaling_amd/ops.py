@@ -283,6 +283,7 @@ def _chain_width_ok(C: int) -> bool:
 # The pair-split kernel walks the 4C hidden units of its 128 rows serially (48 chunks at C = 384: 85 us however few rows there
 # are); below this many rows - the forward-only configurations, M = 6 400 at stage 2 of config #2 - the two ring GEMMs
 # (csrc/gemm_mfma.hip::gemm_nt_ring_kernel: 25 + 20 us) are faster.
+_NO_CHAIN_LN = os.environ.get('VKAS_NO_CHAIN_LN') is not None  # A/B switch: LayerNorm as its own launch in front of the fused MLP
 _CHAIN_PAIR_MIN_ROWS = int(os.environ.get('VKAS_MLP_CHAIN_PAIR_MIN_ROWS', '16384'))
 
 
@@ -1346,17 +1347,38 @@ class ConvNextLayer(Function):
         _timed(dw_fwd_name, x, 2.0 * 49 * M * C, M, Cp, 49,
                lambda: check(lib.vkas_dwconv7x7_fwd(_p(x), act_ld(x), _p(wdw), _p(dwb), None, 0, _p(y), Cp, B, H, W, Cp, dt,
                                                     st), 'dwconv7x7_fwd'), 2.0 * M * Cp * x.element_size())
-        # LayerNorm
-        yn, stats = layernorm_fwd(y, ln_g.contiguous(), ln_b.contiguous(), C, False)
-        # MLP
         C4 = w1.shape[0]
         C4p = rup8(C4)
+        chain = C4 == 4 * C and mlp_chain_eligible(x, C)
+        # LayerNorm: inside the fused MLP kernel where that runs (the rows are normalised on their way into the first matrix
+        # product; yn / stats are written for backward only), its own launch otherwise
+        fuse_ln = chain and not _NO_CHAIN_LN
+        if not fuse_ln:
+            yn, stats = layernorm_fwd(y, ln_g.contiguous(), ln_b.contiguous(), C, False)
+        # MLP
         out = new_act(B, H, W, Cp, x)
         z = new_act(B, H, W, Cp, x)
         cs = pad_vector(block_scale, Cp)
         rs = None if rowscale is None else rowscale.to(_FLOAT).contiguous()
-        chain = C4 == 4 * C and mlp_chain_eligible(x, C)
-        if chain:
+        if chain and fuse_ln:
+            h = new_act(B, H, W, C4p, x) if keep else None
+            yn = new_act(B, H, W, Cp, x) if keep else None
+            stats = torch.empty((M, 2), dtype=_FLOAT, device=x.device) if keep else None
+            if not keep:
+                z = None
+            g = None
+            img = pack_mlp_chain(w1, w2, b1, C, 0, x.dtype)
+            es = x.element_size()
+            lg, lb = pad_vector(ln_g.contiguous(), Cp), pad_vector(ln_b.contiguous(), Cp)
+            _timed('mlp_chain_pair_kernel<fwd>' if 256 < C <= 384 else 'mlp_chain_kernel<fwd>', x, 4.0 * M * C * C4, M, C, C4,
+                   lambda: check(lib.vkas_mlp_chain_ln_fwd(_p(y), Cp, _p(lg), _p(lb), _p(yn), Cp, _p(stats), _p(img),
+                                                           _p(pad_vector(b2, Cp)), _p(x), act_ld(x), _p(cs), _p(rs), H * W,
+                                                           _p(h), C4p, _p(z), Cp, _p(out), Cp, M, C, dt, st),
+                                 'mlp_chain_ln_fwd'),
+                   float(M) * ((5 * Cp + C4p) if keep else 3 * Cp) * es)
+            if not keep:
+                return out
+        elif chain:
             # one kernel: h = yn W1^T + b1 is written once (for backward), gelu(h) goes from the first matrix product
             # into the second in registers, the layer-scale / stochastic-depth / residual epilogue follows
             h = new_act(B, H, W, C4p, x) if keep else None
