@@ -158,8 +158,20 @@ __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
 // lanes fr, fr + 16, fr + 32, fr + 48 (k = ks*32 + g*8 .. +7), so the statistics are per-lane sums + two cross-lane steps;
 // two-pass in fp32 (mean, then centred variance, eps = 1e-6) and the same expression per element as layernorm_fwd_kernel
 // (norm.hip), rounded to the storage type once.  mrow(i) = global row of this lane's row in group i.
+// gamma | beta -> LDS (2 C floats at lnp), requested in FRONT of the row loads so that the two travel together: read from
+// global memory inside chain_layernorm_rows they were a second, dependent round trip in every workgroup's prologue.
+template <int NTHR>
+__device__ __forceinline__ void chain_layernorm_stage(const ChainArgs& p, float* lnp, int tid) {
+  const int cq = p.C >> 2;  // float4 pieces per vector (C % 8 == 0)
+  for (int i = tid; i < 2 * cq; i += NTHR) {
+    const bool hi = i >= cq;
+    const int idx = hi ? i - cq : i;
+    *reinterpret_cast<float4*>(lnp + (hi ? p.C : 0) + idx * 4) = *reinterpret_cast<const float4*>((hi ? p.ln_beta : p.ln_gamma) + idx * 4);
+  }
+}
+
 template <typename T, int TM, int KS, typename V8, typename RowFn>
-__device__ __forceinline__ void chain_layernorm_rows(V8 (&xf)[TM][KS], const ChainArgs& p, RowFn mrow, int g) {
+__device__ __forceinline__ void chain_layernorm_rows(V8 (&xf)[TM][KS], const ChainArgs& p, RowFn mrow, int g, const float* lnp) {
   const int C = p.C;
   float mean[TM], rstd[TM];
 #pragma unroll
@@ -193,8 +205,8 @@ __device__ __forceinline__ void chain_layernorm_rows(V8 (&xf)[TM][KS], const Cha
     const int k = ks * 32 + g * 8;
     const bool k_ok = k < C;
     float gv[8], bv[8];
-    load8(p.ln_gamma + (k_ok ? k : 0), gv);
-    load8(p.ln_beta + (k_ok ? k : 0), bv);
+    load8(lnp + (k_ok ? k : 0), gv);
+    load8(lnp + C + (k_ok ? k : 0), bv);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const long m = mrow(i);
@@ -338,6 +350,9 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
   // input rows -> B fragments (row fr of group i, k = ks*32 + g*8 .. +7), resident for the whole kernel
   v8 xf[TM][KS];
   const T* A = reinterpret_cast<const T*>(p.a);
+  float* lnp = reinterpret_cast<float*>(lds + 2 * IMG);  // the staging region is idle until the first chunk
+  static_assert(4 * STG * (int)sizeof(T) >= 2 * 512 * 4, "LayerNorm parameters fit the staging region");
+  const bool fused_ln = MODE == MODE_FWD && p.ln_gamma != nullptr;  // workgroup-uniform
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const long m = row0 + i * 16 + fr;
@@ -350,7 +365,11 @@ __global__ __launch_bounds__(256, MINB) void mlp_chain_kernel(ChainArgs p) {
     }
   }
   if constexpr (MODE == MODE_FWD) {
-    if (p.ln_gamma) chain_layernorm_rows<T, TM, KS>(xf, p, [&](int i) { return row0 + i * 16 + fr; }, g);
+    if (fused_ln) {
+      chain_layernorm_stage<256>(p, lnp, tid);
+      __syncthreads();
+      chain_layernorm_rows<T, TM, KS>(xf, p, [&](int i) { return row0 + i * 16 + fr; }, g, lnp);
+    }
   }
   f32x4 acc[TM][NT2];
 #pragma unroll
@@ -818,7 +837,12 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(ChainArgs p) {
     }
   }
   if constexpr (MODE == MODE_FWD) {
-    if (p.ln_gamma) chain_layernorm_rows<T, TM, KS>(xf, p, [&](int i) { return row0 + (t * TM + i) * 16 + fr; }, g);
+    if (p.ln_gamma) {  // workgroup-uniform; the staging region is idle until the first VALU phase
+      float* lnp = reinterpret_cast<float*>(lds + OFF_STG);
+      chain_layernorm_stage<512>(p, lnp, tid);
+      __syncthreads();
+      chain_layernorm_rows<T, TM, KS>(xf, p, [&](int i) { return row0 + (t * TM + i) * 16 + fr; }, g, lnp);
+    }
   }
   f32x4 acc[RG][KS];
 #pragma unroll
