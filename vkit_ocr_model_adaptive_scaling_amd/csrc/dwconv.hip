@@ -416,35 +416,6 @@ __global__ __launch_bounds__(512, 4) void dwconv7x7_mfma_kernel(const T* __restr
   constexpr int NITEM = MIY * MIX * 2, NSTG = (NITEM + NTHR - 1) / NTHR;
   for (int i = tid; i < 16 * MPB_IN / 2; i += NTHR) reinterpret_cast<unsigned*>(in_planes)[i] = 0u;  // margins stay zero
 
-  // band matrices of this wave's 4 channels: A_ky[i][k], lane = (i, k = 8g .. 8g+7).  The slice's 49 x 16 weights go
-  // through LDS (the result planes are idle): per-lane gathers straight from global memory would keep 224 loads in flight
-  for (int i = tid; i < 49 * 16; i += NTHR) {
-    const int tap = i >> 4, cl = i & 15;
-    out_planes[i] = (c0 + cl < Cp) ? w[(long)tap * Cp + c0 + cl] : 0.f;
-  }
-  __syncthreads();
-  v8 af[2][7];
-#pragma unroll
-  for (int cc = 0; cc < 2; ++cc) {
-    const int cl = wave * 2 + cc;
-#pragma unroll
-    for (int ky = 0; ky < 7; ++ky) {
-      v8 a;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int tap = 8 * g + e - li - 5;
-        const bool ok = tap >= 0 && tap < 7;
-        const float v = out_planes[((ky * 7 + (ok ? tap : 0)) << 4) + cl];
-        a[e] = (T)(ok ? v : 0.f);
-      }
-      af[cc][ky] = a;
-    }
-    asm volatile("" ::: "memory");  // one channel's 56 reads at a time
-  }
-  float bv[2];
-#pragma unroll
-  for (int cc = 0; cc < 2; ++cc) bv[cc] = (bias && c0 + wave * 2 + cc < Cp) ? bias[c0 + wave * 2 + cc] : 0.f;
-
   auto decode = [&](int t, int& b, int& y0, int& x0) {
     const int tx = t % tiles_x;
     const int q = t / tiles_x;
@@ -483,6 +454,40 @@ __global__ __launch_bounds__(512, 4) void dwconv7x7_mfma_kernel(const T* __restr
       sv[k] = v;
     }
   };
+  int t = walker;
+  if (t >= nsp) return;
+  // the first halo tile is requested in front of the weight table: the two round trips to memory of a workgroup's prologue
+  // travel together (at small maps - one or two tiles per workgroup - the prologue is most of the launch)
+  fetch(t);
+  // band matrices of this wave's 4 channels: A_ky[i][k], lane = (i, k = 8g .. 8g+7).  The slice's 49 x 16 weights go
+  // through LDS (the result planes are idle): per-lane gathers straight from global memory would keep 224 loads in flight
+  for (int i = tid; i < 49 * 16; i += NTHR) {
+    const int tap = i >> 4, cl = i & 15;
+    out_planes[i] = (c0 + cl < Cp) ? w[(long)tap * Cp + c0 + cl] : 0.f;
+  }
+  __syncthreads();
+  v8 af[2][7];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    const int cl = wave * 2 + cc;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+      v8 a;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int tap = 8 * g + e - li - 5;
+        const bool ok = tap >= 0 && tap < 7;
+        const float v = out_planes[((ky * 7 + (ok ? tap : 0)) << 4) + cl];
+        a[e] = (T)(ok ? v : 0.f);
+      }
+      af[cc][ky] = a;
+    }
+    asm volatile("" ::: "memory");  // one channel's 56 reads at a time
+  }
+  float bv[2];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) bv[cc] = (bias && c0 + wave * 2 + cc < Cp) ? bias[c0 + wave * 2 + cc] : 0.f;
+
   // channel 8*chunk + k of the slice -> plane 2k + chunk (the two chunk lanes of a pixel land 24 banks apart)
   auto stage = [&]() {
 #pragma unroll
@@ -502,9 +507,6 @@ __global__ __launch_bounds__(512, 4) void dwconv7x7_mfma_kernel(const T* __restr
     }
   };
 
-  int t = walker;
-  if (t >= nsp) return;
-  fetch(t);
   __syncthreads();  // zero fill done, the weight table in the result planes has been read
   stage();
   __syncthreads();
