@@ -182,7 +182,7 @@ int vkas_mlp_chain_ln_fwd(const void* y, long ldy, const float* ln_gamma, const 
 int vkas_mlp_chain_bwd(const void* dz, long lddz, const void* img_t, const void* h, long ldh, void* dh, long lddh,
                        void* dyn, long lddyn, long M, int C, int dtype, void* stream);
 /* profiling aid: tile configuration a bf16 call of these sizes runs.  fwd (wgrad == 0): 1 = 128x128 (4 waves), else the
- * N extent 128 / 192 / 224 of the 256-row 8-wave tile; wgrad: N extent 128 (4 waves) or 192 / 224 (8 waves); 0 when the
+ * N extent 128 / 192 / 224 of the 256-row 8-wave tile; wgrad: N extent 128 (4 waves), 192 / 224 (8 waves, 256 K columns) or 384 (8 waves, 128 K columns); 0 when the
  * plain fp32-FMA kernels are forced (VKAS_GEMM=simple). */
 int vkas_conv_gemm_tile(int wgrad, long M, int Np, int K);
 /* profiling aid: the kernel a bf16 call with this geometry runs.  0 = plain fp32-FMA kernels forced.  fwd: 1 / 128 / 192 /

@@ -178,7 +178,8 @@ torch.save({'y': y.float().cpu(), 'gx': x.grad.float().cpu(), 'gw': w.grad.cpu()
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
 @pytest.mark.parametrize('variant', ['bias', 'nobias', 'gelu'])
-def test_pointwise_wgrad_8wave_tiles(variant, dtype):
+@pytest.mark.parametrize('shape', [(376, 264, 192), (768, 376, 384)], ids=['tile192', 'tile384'])
+def test_pointwise_wgrad_8wave_tiles(shape, variant, dtype):
     """Weight (and bias) gradient of a pointwise layer at the sizes that take the 8-wave 192-wide tile of gemm_tn_mfma_kernel
     (M >= 16 384 rows): the variant with bias sums (v_dot2c against ones), the one compiled without them (second staging set in
     flight) and the one that applies GELU to the staged operand - ragged M / N / K tails - against fp64 math on the stored
@@ -187,12 +188,13 @@ def test_pointwise_wgrad_8wave_tiles(variant, dtype):
     from vkit_ocr_model_adaptive_scaling_amd import _lib
     import ctypes
     g = torch.Generator().manual_seed(17)
-    M, N, K = 16384 + 72, 376, 264
+    # tile384: N a multiple of 384 and 256 < K <= 384 take the 384 (N) x 128 (K) tile (no zero-padded K tile); K tail ragged
+    M, (N, K, tile) = 16384 + 72, shape
     x = (torch.randn((M, K), generator=g) * 1.5).to(dtype).cuda()
     dy = torch.randn((M, N), generator=g).to(dtype).cuda()
     gw = torch.zeros((N * K + N,), device='cuda')
     geom = _lib.ConvGeom(1, 1, M, 1, M, K, K, 1, 1, 1, 0)
-    assert _lib.lib.vkas_conv_gemm_kernel_id(1, ctypes.byref(geom), N, N, 0) == 192
+    assert _lib.lib.vkas_conv_gemm_kernel_id(1, ctypes.byref(geom), N, N, 0) == tile
     fn = _lib.lib.vkas_conv_gemm_wgrad_gelu if variant == 'gelu' else _lib.lib.vkas_conv_gemm_wgrad
     gb = None if variant == 'nobias' else gw.data_ptr() + 4 * N * K
     rc = fn(x.data_ptr(), ctypes.byref(geom), dy.data_ptr(), N, N, gw.data_ptr(), gb,

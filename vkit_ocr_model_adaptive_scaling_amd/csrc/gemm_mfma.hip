@@ -1101,7 +1101,8 @@ __global__ __launch_bounds__(WN* WK * 64) void gemm_tn_mfma_kernel(const elem_t*
   // the 192-wide tile with one set: profiles/experiments/README.md)
   // (four 512-register waves of 96 x 128 - 14 fragments per 48 products instead of 10 per 24 - were compiled: the 192 accumulators
   // go to AGPRs, but staging sets + fragments exceed the 256 architectural registers and spill, with or without the second set)
-  constexpr bool DEEP = VKAS_TN_DEEP && PW && TNn <= 6 && !XG && NOBIAS && WN * WK >= (VKAS_TN_DEEP > 1 ? 4 : 8);
+  // (the 384 x 128 tile stages 6 + 2 chunks per thread: its second set spills 16 dwords)
+  constexpr bool DEEP = VKAS_TN_DEEP && PW && TNn <= 6 && !XG && NOBIAS && WN * WK >= (VKAS_TN_DEEP > 1 ? 4 : 8) && DCH + XCH <= 7;
   elem8 rdA[DCH], rxA[XCH], rdB[DEEP ? DCH : 1], rxB[DEEP ? XCH : 1];
   long mcur = mbeg;
   auto load_tile = [&](elem8 (&rd)[DCH], elem8 (&rx)[XCH]) {
@@ -1816,7 +1817,7 @@ static void launch_tn(const void* x, const vkas_conv_geom* g, const void* dy, lo
 }
 
 #ifndef VKAS_MFMA_F16
-// Tile choice of the TN (wgrad) kernel: N extent 128 (4 waves, 128 K columns) or 192 / 224 (8 waves, 256 K columns):
+// Tile choice of the TN (wgrad) kernel: N extent 128 (4 waves, 128 K columns), 192 / 224 (8 waves, 256 K columns) or 384 (8 waves, 128 K columns):
 // 8-wave tiles when there is enough work and K is wide enough; N extent = least zero padding.
 int vkas_gemm_tn_tile_choice(long M, int Np, int K) {
   static const int force = getenv("VKAS_TN_TILE") ? atoi(getenv("VKAS_TN_TILE")) : 0;
@@ -1832,6 +1833,9 @@ int vkas_gemm_tn_tile_choice(long M, int Np, int K) {
         bn = cand[c];
       }
     }
+    // 384 (N) x 128 (K) instead of 192 x 256 - the same 96 x 64 per wave - where the 256-wide K tiles would be padded and the
+    // 128-wide ones are not (K = 384: the W1 weight gradient of a C = 384 ConvNeXt MLP ran a quarter of its products on zeros)
+    if (bn == 192 && Np % 384 == 0 && vkas_cdiv(K, 128) * 128 < vkas_cdiv(K, 256) * 256) bn = 384;
   }
   return bn;
 }
@@ -1877,7 +1881,10 @@ int VKAS_MFMA_FN(vkas_gemm_tn_mfma)(const void* x, const vkas_conv_geom* g, cons
     return VKAS_OK;
   }
   const int bn = vkas_gemm_tn_tile_choice(M, Np, K);
-  if (x_gelu) {
+  if (bn == 384) {
+    if (x_gelu) launch_tn<4, 2, 6, 4, true>(x, g, dy, lddy, Np, M, K, gw, gb, one_split, st);
+    else launch_tn<4, 2, 6, 4, false>(x, g, dy, lddy, Np, M, K, gw, gb, one_split, st);
+  } else if (x_gelu) {
     if (bn == 224) launch_tn<2, 4, 7, 4, true>(x, g, dy, lddy, Np, M, K, gw, gb, one_split, st);
     else if (bn == 192) launch_tn<2, 4, 6, 4, true>(x, g, dy, lddy, Np, M, K, gw, gb, one_split, st);
     else launch_tn<2, 2, 4, 4, true>(x, g, dy, lddy, Np, M, K, gw, gb, one_split, st);

@@ -375,7 +375,7 @@ def tn_kernel_name(kid: int) -> str:
         return 'gemm_tn_simple'
     if kid >= 2000:
         return 'conv3x3_wgrad_slab_kernel<%d>' % (kid - 2000)
-    return 'gemm_tn_mfma_kernel<%s>' % {128: '2,2,4,4', 192: '2,4,6,4', 224: '2,4,7,4'}[kid]
+    return 'gemm_tn_mfma_kernel<%s>' % {128: '2,2,4,4', 192: '2,4,6,4', 224: '2,4,7,4', 384: '4,2,6,4'}[kid]
 
 
 def _timed(kind, x, flops, M, N, K, fn, nbytes=0.0):
