@@ -38,6 +38,20 @@ def test_argument_validation_without_gpu():
     with pytest.raises(_lib.VkasError):
         _lib.check(rc, 'conv')
     assert _lib.lib.vkas_layernorm_fwd(None, 8, None, None, None, 8, None, 4, 8, 8, 0, 0, None) == -1
+    # fused MLP with LayerNorm: 16-bit storage only, LayerNorm parameters required, the backward operands travel together
+    P = ctypes.c_void_p
+    a = lambda: P(256)  # any aligned non-null address: the checks run before anything is dereferenced or launched
+    ln = _lib.lib.vkas_mlp_chain_ln_fwd
+    assert ln(a(), 96, a(), a(), None, 96, None, a(), a(), a(), 96, a(), None, 64, None, 384, None, 96, a(), 96, 128, 96,
+              _lib.F32, None) == -1 and b'16-bit' in _lib.lib.vkas_last_error()
+    assert ln(a(), 96, None, a(), None, 96, None, a(), a(), a(), 96, a(), None, 64, None, 384, None, 96, a(), 96, 128, 96,
+              _lib.BF16, None) == -1 and b'LayerNorm parameter' in _lib.lib.vkas_last_error()
+    assert ln(a(), 96, a(), a(), a(), 96, None, a(), a(), a(), 96, a(), None, 64, None, 384, None, 96, a(), 96, 128, 96,
+              _lib.BF16, None) == -1 and b'together' in _lib.lib.vkas_last_error()
+    assert ln(a(), 96, a(), a(), None, 96, None, a(), a(), a(), 96, a(), None, 64, None, 384, None, 96, a(), 96, 128, 100,
+              _lib.BF16, None) == -1 and b'not covered' in _lib.lib.vkas_last_error()
+    assert ln(a(), 96, a(), a(), None, 96, None, a(), a(), a(), 96, a(), None, 64, None, 384, None, 96, a(), 96, 0, 96,
+              _lib.BF16, None) == 0  # M = 0: nothing to do, nothing launched
 
 
 @pytest.mark.parametrize('kind', ['upernext', 'fpn'])
