@@ -657,7 +657,7 @@ __global__ __launch_bounds__(512, 4) void dwconv7x7_wgrad_mfma_kernel(const T* _
       const int gy = y0 + iy - 3, gx = x0 + ix - 3;
       const int c = c0 + chunk * 8;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (it < NXI && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cp)
+      if (it < NXI && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cp && !(DW_ABL & 1024))
         v = *reinterpret_cast<const uint4*>(x + (((long)b * H + gy) * W + gx) * ldx + c);
       sx[k] = v;
     }
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(512, 4) void dwconv7x7_wgrad_mfma_kernel(const T* _
       const int gy = y0 + oy, gx = x0 + ox;
       const int c = c0 + chunk * 8;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (gy < H && gx < W && c < Cp) v = *reinterpret_cast<const uint4*>(dy + (((long)b * H + gy) * W + gx) * lddy + c);
+      if (gy < H && gx < W && c < Cp && !(DW_ABL & 1024)) v = *reinterpret_cast<const uint4*>(dy + (((long)b * H + gy) * W + gx) * lddy + c);
       sd[k] = v;
     }
   };
@@ -683,6 +683,13 @@ __global__ __launch_bounds__(512, 4) void dwconv7x7_wgrad_mfma_kernel(const T* _
     }
   };
   auto stage = [&]() {
+    if (DW_ABL & 256) {  // timing only (weight gradient: 256 no staging writes, 512 no products, 1024 no global loads)
+#pragma unroll
+      for (int k = 0; k < NXS; ++k) asm volatile("" ::"v"(sx[k].x), "v"(sx[k].y), "v"(sx[k].z), "v"(sx[k].w));
+#pragma unroll
+      for (int k = 0; k < NDS; ++k) asm volatile("" ::"v"(sd[k].x), "v"(sd[k].y), "v"(sd[k].z), "v"(sd[k].w));
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < NXS; ++k) {
       const int it = tid + k * NTHR;
@@ -720,7 +727,7 @@ __global__ __launch_bounds__(512, 4) void dwconv7x7_wgrad_mfma_kernel(const T* _
       const bool more = t + wg_per_slice < nsp;
       if (more) fetch(t + wg_per_slice);
 #pragma unroll
-      for (int cc = 0; cc < 2; ++cc) {
+      for (int cc = 0; cc < ((DW_ABL & 512) ? 0 : 2); ++cc) {
         const int cl = wave * 2 + cc;
         const int P = (cl & 7) * 2 + (cl >> 3);
         const unsigned* xrow = reinterpret_cast<const unsigned*>(xp + P * WPB_X) + (eo >> 1);
